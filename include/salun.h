@@ -1,0 +1,218 @@
+/*
+ * salun.h — C-ABI of the MI355X-native SalUn hot path (libsalun.so, gfx950).
+ *
+ * This is the drop-in boundary.  The reference
+ * (OPTML-Group/Unlearn-Saliency) is 100 % Python and has no FFI of its own; each
+ * entry point below replaces a *sequence of stock ATen launches* issued from a
+ * Python loop over parameter tensors.  The reference sequence every function
+ * replaces is cited as  <file>:<lines>  relative to the reference checkout.
+ *
+ * Conventions (all functions):
+ *   - plain pointers and sizes only; no torch / HIP types in the signatures.
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - every pointer marked "dev" is a device pointer owned by the caller; nothing
+ *     is retained after return; all work is stream-ordered, nothing synchronises
+ *     the host, nothing allocates.  Scratch memory is passed in by the caller
+ *     (`ws`, `ws_bytes`), sized by the matching *_workspace_bytes() query.
+ *   - return value: 0 (SALUN_OK) or a negative errno-style code; never throws,
+ *     never aborts.  salun_strerror() names a code.
+ *   - vectors are the *flat* concatenation of all parameter tensors in
+ *     named_parameters() order, each tensor row-major.
+ *     Pointers should be 16-byte aligned for the fast path; any alignment is
+ *     accepted (a scalar path is used).
+ *   - masks are uint8 0/1 (1 byte per weight) inside the library; the reference's
+ *     on-disk format (int64 0/1) is produced/consumed by the two converters.
+ *   - fp32 arithmetic is IEEE round-to-nearest with the operation order stated
+ *     per function (compiled with -ffp-contract=off; fused multiply-adds appear
+ *     only where written as fma()).  oracle/salun_oracle.c restates exactly the
+ *     same order on the CPU, so GPU-vs-oracle comparisons are bit-exact for the
+ *     element-wise kernels and for the mask.
+ */
+#ifndef SALUN_H
+#define SALUN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SALUN_OK 0
+#define SALUN_EINVAL (-22)   /* bad argument (null pointer, negative size, nk out of range) */
+#define SALUN_ENOSPC (-28)   /* workspace too small */
+#define SALUN_EIO (-5)       /* HIP launch / runtime error */
+
+#define SALUN_MAX_THRESHOLDS 16
+
+typedef void *salun_stream_t; /* hipStream_t */
+
+/* Library identification: major*10000 + minor*100 + patch. */
+int salun_version(void);
+/* Static string for a return code. */
+const char *salun_strerror(int code);
+/* Target ISA the kernels were compiled for ("gfx950"). */
+const char *salun_arch(void);
+
+/* ------------------------------------------------------------------ K1 --
+ * Saliency accumulation:   acc[i] <- acc[i] + (g[i] * scale)      (2 roundings)
+ * Replaces the per-tensor loop  `gradients[name] += param.grad.data`
+ *   Classification/generate_mask.py:41-44, DDPM/runners/diffusion.py:992-996,
+ *   SD/train-scripts/generate_mask.py:66-69,171-174.
+ * scale = 1 for Classification/SD.  For DDPM the per-batch clip of
+ * runners/diffusion.py:985-990 is folded in: if `sqnorm` (dev, 1 float, the
+ * squared global L2 norm of g from salun_grad_sqnorm) is non-NULL the scale is
+ * computed on the device as  min(1, max_norm / (sqrt(*sqnorm) + 1e-6))  — the
+ * clip_grad_norm_ coefficient — and `scale` is ignored.
+ * Algorithmic traffic: 12 B / element. */
+int salun_saliency_accumulate(float *acc /*dev*/, const float *g /*dev*/,
+                              double scale, const float *sqnorm /*dev or NULL*/,
+                              double max_norm, int64_t n, salun_stream_t stream);
+
+/* ------------------------------------------------------------------ K2 --
+ * Global top-k saliency mask for nk thresholds at once.
+ * Replaces  abs_ -> -cat(flatten) -> argsort -> argsort -> (ranks < k)
+ *   Classification/generate_mask.py:46-80, DDPM/runners/diffusion.py:998-1037,
+ *   SD/train-scripts/generate_mask.py:71-106,176-209.
+ * For threshold j:  masks_out[j][i] = 1  iff  rank_desc(|acc[i]|) < ks[j], where
+ * rank_desc orders by |acc| descending, ties by flat index ascending (the
+ * `argsort(stable=True)` reading of the reference) and NaN
+ * after every number.  popcount(masks_out[j]) == min(max(ks[j],0), n) exactly.
+ * `acc` is NOT modified (the abs is fused).  ks[] and masks_out[] are HOST
+ * arrays (read before return); masks_out[j] are device pointers to n bytes.
+ * 1 <= nk <= SALUN_MAX_THRESHOLDS.
+ * Algorithmic traffic: 4 B read + nk B written per element. */
+size_t salun_mask_topk_workspace_bytes(int64_t n, int nk);
+int salun_mask_topk(const float *acc /*dev*/, int64_t n, const int64_t *ks /*host*/,
+                    int nk, uint8_t *const *masks_out /*host array of dev ptrs*/,
+                    void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+/* After salun_mask_topk on the same ws: copies the nk selected thresholds
+ * (as fp32 |acc| values; NaN if the k-th element is a NaN) to a host-visible
+ * device array — diagnostic only, 4*nk bytes. */
+int salun_mask_topk_thresholds(const void *ws /*dev*/, int nk, float *tau_out /*dev*/,
+                               salun_stream_t stream);
+
+/* Mask format converters for the file boundary (reference masks are int64 0/1
+ * tensors: `torch.zeros_like(tensor_ranks)`, generate_mask.py:76-79).
+ * i64 -> u8 maps any non-zero to 1. */
+int salun_mask_u8_to_i64(const uint8_t *m /*dev*/, int64_t *out /*dev*/, int64_t n,
+                         salun_stream_t stream);
+int salun_mask_i64_to_u8(const int64_t *m /*dev*/, uint8_t *out /*dev*/, int64_t n,
+                         salun_stream_t stream);
+/* Number of ones -> *count (dev, 1 int64). Workspace: salun_reduce_workspace_bytes(n). */
+int salun_mask_popcount(const uint8_t *m /*dev*/, int64_t n, int64_t *count /*dev*/,
+                        void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+
+/* --------------------------------------------------------------- K3+K4 --
+ * Masked SGD-momentum step, one launch for the whole model.
+ * Replaces  _apply_mask_to_grads -> torch.optim.SGD.step -> _restore_masked_params
+ *   Classification/unlearn/RL.py:11-14, unlearn/impl.py:68-73 (SGD, dampening 0,
+ *   nesterov off), RL.py:17-34  (same helpers in GA.py/FT.py/boundary_*.py and
+ *   trainer/train.py:58-61,104-107).
+ * Where m[i]==1 (or m==NULL: unmasked plain SGD):
+ *     d   = fma(wd, p, g)                     (d = g when wd == 0)
+ *     buf = first_step ? d : (mu*buf) + d     (mu*buf rounded, then added)
+ *     p   = fma(-lr, buf, p)
+ * Where m[i]==0:  p is left bit-identical (it equals theta0 by the invariant the
+ * reference's restore enforces every step), buf = 0.
+ * `mu == 0` means "no momentum": buf is neither read nor written, may be NULL.
+ * lr/mu/wd are doubles (Python floats) rounded to fp32 once, as torch does.
+ * Algorithmic traffic: 21 B / element (r p,g,buf,m ; w p,buf). */
+int salun_masked_sgd_step(float *p /*dev*/, const float *g /*dev*/, float *buf /*dev*/,
+                          const uint8_t *m /*dev or NULL*/, double lr, double mu,
+                          double wd, int first_step, int64_t n, salun_stream_t stream);
+
+/* ------------------------------------------------------------------ K5 --
+ * Squared global L2 norm of the flat gradient: *out = sum_i g[i]^2  (fp32 result,
+ * accumulated per thread in fp32 lanes and across threads/blocks in fp64, fixed
+ * reduction tree => run-to-run deterministic).
+ * Replaces the per-tensor norms of torch.nn.utils.clip_grad_norm_
+ *   DDPM/runners/diffusion.py:582-587,985-990.
+ * Algorithmic traffic: 4 B / element. */
+size_t salun_reduce_workspace_bytes(int64_t n);
+int salun_grad_sqnorm(const float *g /*dev*/, int64_t n, float *out /*dev*/,
+                      void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+
+/* Masked Adam step (clip -> mask -> Adam), one launch for the whole model.
+ * Replaces  clip_grad_norm_ -> `param.grad *= mask[name].to(device)` -> Adam.step
+ *   DDPM/runners/diffusion.py:582-593 with DDPM/functions/__init__.py:9-18
+ *   (Adam, amsgrad off), SD/train-scripts/random_label.py:129-139,
+ *   SD/train-scripts/nsfw_removal.py:150-160.
+ *     s   = sqnorm ? min(1, max_norm/(sqrt(*sqnorm)+1e-6)) : gscale
+ *     ge  = (g*s) * m                 (m==NULL: ge = g*s)
+ *     ge  = fma(wd, p, ge)            (only when wd != 0)
+ *     m1  = (b1*m1) + ((1-b1)*ge)
+ *     v   = (b2*v)  + ((1-b2)*ge)*ge
+ *     den = sqrt(v)/sqrt(1-b2^step) + eps
+ *     p   = p + (-(lr/(1-b1^step))) * (m1/den)
+ * Hyper-parameters are doubles (Python floats); 1-b1, 1-b2, the bias corrections
+ * and lr/(1-b1^step) are evaluated on the host in double and only then rounded to
+ * fp32, like the Python scalars torch.optim.Adam hands to its fp32 kernels.
+ * step is 1-based.  Algorithmic traffic: 29 B / element. */
+int salun_masked_adam_step(float *p /*dev*/, const float *g /*dev*/, float *m1 /*dev*/,
+                           float *v /*dev*/, const uint8_t *mask /*dev or NULL*/,
+                           const float *sqnorm /*dev or NULL*/, double max_norm,
+                           double gscale, double lr, double b1, double b2, double eps,
+                           double wd, int step, int64_t n, salun_stream_t stream);
+
+/* ------------------------------------------------------------------ K6 --
+ * Forward diffusion sample:  xt = x0*sqrt_ab[t[b]] + e*sqrt_1mab[t[b]]
+ * Replaces  DDPM/functions/losses.py:31-32, runners/diffusion.py:558-559,973-974.
+ * x0,e,xt: (B, chw) row-major; sqrt_ab/sqrt_1mab: (T,) tables; t: (B,) int64. */
+int salun_qsample(const float *x0 /*dev*/, const float *e /*dev*/,
+                  const float *sqrt_ab /*dev*/, const float *sqrt_1mab /*dev*/,
+                  const int64_t *t /*dev*/, int64_t T, float *xt /*dev*/, int64_t B,
+                  int64_t chw, salun_stream_t stream);
+
+/* Squared-error loss + gradient in one pass over (B, chw) tensors a and b:
+ *     per_sample[s] = sum_j (a[s,j]-b[s,j])^2          (optional output)
+ *     *loss         = coef * sum_s per_sample[s]
+ *     dloss_db[s,j] = -2*coef*(a[s,j]-b[s,j])           (optional output)
+ * eps-MSE  `(e-out).square().sum((1,2,3)).mean(0)`  = (a=e, b=out, coef=1/B)
+ *   DDPM/functions/losses.py:34-37, runners/diffusion.py:980;
+ * nn.MSELoss(pseudo, out) = (a=pseudo, b=out, coef=1/(B*chw))
+ *   runners/diffusion.py:507,570, SD random_label.py:113-127.
+ * Reduction order is fixed (deterministic).  Workspace: salun_sqerr_workspace_bytes(B, chw). */
+size_t salun_sqerr_workspace_bytes(int64_t B, int64_t chw);
+int salun_sqerr_loss(const float *a /*dev*/, const float *b /*dev*/, int64_t B,
+                     int64_t chw, double coef, float *loss /*dev*/,
+                     float *per_sample /*dev or NULL*/, float *dloss_db /*dev or NULL*/,
+                     void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+
+/* ------------------------------------------------------------------ K7 --
+ * Diagonal empirical Fisher accumulation:  F += (tmp*tmp)/n_data ; tmp = 0.
+ * Replaces  DDPM/runners/diffusion.py:176-183
+ *   (`fisher += tmp**2 / len(dataset)`, then tmp re-zeroed).   16 B / element. */
+int salun_fim_square_accumulate(float *F /*dev*/, float *tmp /*dev*/, double n_data,
+                                int64_t n, salun_stream_t stream);
+
+/* ------------------------------------------------------------------ K0 --
+ * Device-resident CIFAR batch assembly (replaces the host DataLoader path
+ * Classification/dataset.py:542-556 + main_random.py:38-48: PIL RandomCrop(32,4)
+ * + RandomHorizontalFlip + ToTensor + H2D).
+ * data: (num, H, W, C) uint8 resident in HBM; idx: (B,) int64 sample indices;
+ * crop: (B,2) int32 (dy,dx) offsets in [0, 2*pad] or NULL (= centred, no crop);
+ * flip: (B,) uint8 or NULL; out: (B, C, H, W) fp32 = pixel/255 (ToTensor),
+ * zero padding outside the image. */
+int salun_image_batch(const uint8_t *data /*dev*/, const int64_t *idx /*dev*/,
+                      const int32_t *crop /*dev or NULL*/, const uint8_t *flip /*dev or NULL*/,
+                      float *out /*dev*/, int64_t B, int H, int W, int C, int pad,
+                      salun_stream_t stream);
+
+/* Counter-based generators shared bit-for-bit with oracle/ (splitmix64 of
+ * seed + index; integer arithmetic only, so CPU and GPU agree exactly):
+ *   uniform: lo + (hi-lo) * (top 24 bits / 2^24);
+ *   normal : mean + std * z, z = (sum of twelve 16-bit chunks of three
+ *            splitmix64 outputs - 393210) / 65536  (Irwin-Hall 12: mean 0, var 1);
+ *   u8     : byte (index & 7) of splitmix64(seed + (index >> 3)).
+ * Used to regenerate identical synthetic inputs on any machine. */
+int salun_fill_uniform(float *out /*dev*/, int64_t n, uint64_t seed, double lo, double hi,
+                       salun_stream_t stream);
+int salun_fill_normal(float *out /*dev*/, int64_t n, uint64_t seed, double mean, double std,
+                      salun_stream_t stream);
+int salun_fill_u8(uint8_t *out /*dev*/, int64_t n, uint64_t seed, salun_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SALUN_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of libsalun.so — the C-ABI declared in include/salun.h.
+
+The library is built in-tree (``make -C unlearn_saliency_amd/csrc`` or
+``__graft_entry__.build()``) and loaded from this directory.  There is no CPU
+fallback anywhere in this package: if the shared object is missing or a symbol is
+absent, importing callers get a loud ``ImportError`` / ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsalun.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+SALUN_OK = 0
+SALUN_MAX_THRESHOLDS = 16
+
+c_void_p, c_int, c_int64, c_uint64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
+c_double, c_size_t = ctypes.c_double, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/salun.h one to one
+# (tests/test_cabi.py checks this table against the header and the .so).
+SIGNATURES = {
+    "salun_version": (c_int, []),
+    "salun_strerror": (ctypes.c_char_p, [c_int]),
+    "salun_arch": (ctypes.c_char_p, []),
+    "salun_saliency_accumulate": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_double, c_int64, c_void_p]),
+    "salun_mask_topk_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "salun_mask_topk": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_int64), c_int, ctypes.POINTER(c_void_p),
+                                c_void_p, c_size_t, c_void_p]),
+    "salun_mask_topk_thresholds": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "salun_mask_u8_to_i64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "salun_mask_i64_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "salun_mask_popcount": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "salun_masked_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_int,
+                                      c_int64, c_void_p]),
+    "salun_reduce_workspace_bytes": (c_size_t, [c_int64]),
+    "salun_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "salun_masked_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
+                                       c_double, c_double, c_double, c_double, c_double, c_double, c_int, c_int64,
+                                       c_void_p]),
+    "salun_qsample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                              c_void_p]),
+    "salun_sqerr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "salun_sqerr_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
+    "salun_fim_square_accumulate": (c_int, [c_void_p, c_void_p, c_double, c_int64, c_void_p]),
+    "salun_image_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                  c_int, c_void_p]),
+    "salun_fill_uniform": (c_int, [c_void_p, c_int64, c_uint64, c_double, c_double, c_void_p]),
+    "salun_fill_normal": (c_int, [c_void_p, c_int64, c_uint64, c_double, c_double, c_void_p]),
+    "salun_fill_u8": (c_int, [c_void_p, c_int64, c_uint64, c_void_p]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into libsalun.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j4"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"build did not produce {LIB_PATH}")
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library with argtypes set.  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the SalUn HIP extension has not been built "
+                f"(run `make -C {CSRC_DIR}` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:  # stale .so
+                raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class SalunError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code != SALUN_OK:
+        msg = lib().salun_strerror(code).decode()
+        raise SalunError(f"{what} failed: {msg} ({code})")

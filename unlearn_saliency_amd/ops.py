@@ -1,0 +1,246 @@
+"""Tensor-level wrappers over the C-ABI (include/salun.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every function
+below hands raw device pointers + the current stream to libsalun.so.  All tensors must
+live on a ROCm device (``tensor.is_cuda``); there is deliberately no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p, check
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, allow_none: bool = False) -> c_void_p:
+    if t is None:
+        if allow_none:
+            return c_void_p(None)
+        raise ValueError(f"{name} must not be None")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the SalUn HIP kernels need a device tensor (got {t.device}); no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+# One scratch buffer per device, grown on demand (stream-ordered reuse on the current stream).
+_ws: dict[int, torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _ws.get(idx)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[idx] = w
+    return w
+
+
+# ----------------------------------------------------------------------------- K1
+def saliency_accumulate(acc: torch.Tensor, g: torch.Tensor, scale: float = 1.0,
+                        sqnorm: Optional[torch.Tensor] = None, max_norm: float = 1.0) -> None:
+    """acc += g*scale  (or g * clip_coef(sqnorm, max_norm) when `sqnorm` is given)."""
+    assert acc.numel() == g.numel()
+    check(_lib.lib().salun_saliency_accumulate(_dev(acc, torch.float32, "acc"), _dev(g, torch.float32, "g"),
+                                               c_double(scale), _dev(sqnorm, torch.float32, "sqnorm", True),
+                                               c_double(max_norm), c_int64(acc.numel()), _stream()),
+          "salun_saliency_accumulate")
+
+
+# ----------------------------------------------------------------------------- K2
+def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch.Tensor]] = None
+              ) -> list[torch.Tensor]:
+    """One u8 0/1 mask per k: the k largest |acc| (ties: lowest flat index first)."""
+    L = _lib.lib()
+    n, nk = acc.numel(), len(ks)
+    if not 1 <= nk <= _lib.SALUN_MAX_THRESHOLDS:
+        raise ValueError(f"1 <= len(ks) <= {_lib.SALUN_MAX_THRESHOLDS}")
+    if out is None:
+        out = [torch.empty(n, dtype=torch.uint8, device=acc.device) for _ in ks]
+    assert len(out) == nk and all(o.numel() == n for o in out)
+    nbytes = L.salun_mask_topk_workspace_bytes(c_int64(n), c_int(nk))
+    ws = workspace(nbytes, acc.device)
+    karr = (c_int64 * nk)(*[int(k) for k in ks])
+    marr = (c_void_p * nk)(*[_dev(o, torch.uint8, "mask").value for o in out])
+    check(L.salun_mask_topk(_dev(acc, torch.float32, "acc"), c_int64(n), karr, c_int(nk), marr,
+                            c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()), "salun_mask_topk")
+    return list(out)
+
+
+def mask_topk_thresholds(device: torch.device, nk: int) -> torch.Tensor:
+    """|acc| value of the k-th element for the thresholds of the LAST mask_topk call on this device."""
+    ws = workspace(0, device)
+    out = torch.empty(nk, dtype=torch.float32, device=device)
+    check(_lib.lib().salun_mask_topk_thresholds(c_void_p(ws.data_ptr()), c_int(nk), c_void_p(out.data_ptr()),
+                                                _stream()), "salun_mask_topk_thresholds")
+    return out
+
+
+def mask_u8_to_i64(m: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(m.shape, dtype=torch.int64, device=m.device)
+    check(_lib.lib().salun_mask_u8_to_i64(_dev(m, torch.uint8, "mask"), c_void_p(out.data_ptr()),
+                                          c_int64(m.numel()), _stream()), "salun_mask_u8_to_i64")
+    return out
+
+
+def mask_i64_to_u8(m: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty(m.shape, dtype=torch.uint8, device=m.device)
+    check(_lib.lib().salun_mask_i64_to_u8(_dev(m, torch.int64, "mask"), _dev(out, torch.uint8, "out"),
+                                          c_int64(m.numel()), _stream()), "salun_mask_i64_to_u8")
+    return out
+
+
+def mask_popcount(m: torch.Tensor) -> int:
+    L = _lib.lib()
+    ws = workspace(L.salun_reduce_workspace_bytes(c_int64(m.numel())), m.device)
+    out = torch.empty(1, dtype=torch.int64, device=m.device)
+    check(L.salun_mask_popcount(_dev(m, torch.uint8, "mask"), c_int64(m.numel()), c_void_p(out.data_ptr()),
+                                c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()), "salun_mask_popcount")
+    return int(out.item())
+
+
+# -------------------------------------------------------------------------- K3+K4
+def masked_sgd_step(p: torch.Tensor, g: torch.Tensor, buf: Optional[torch.Tensor], m: Optional[torch.Tensor],
+                    lr: float, momentum: float, weight_decay: float, first_step: bool) -> None:
+    n = p.numel()
+    assert g.numel() == n and (buf is None or buf.numel() == n) and (m is None or m.numel() == n)
+    check(_lib.lib().salun_masked_sgd_step(_dev(p, torch.float32, "p"), _dev(g, torch.float32, "g"),
+                                           _dev(buf, torch.float32, "buf", True), _dev(m, torch.uint8, "mask", True),
+                                           c_double(lr), c_double(momentum), c_double(weight_decay),
+                                           c_int(int(first_step)), c_int64(n), _stream()), "salun_masked_sgd_step")
+
+
+# ----------------------------------------------------------------------------- K5
+def grad_sqnorm(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum(g^2) as a 1-element device tensor (no host sync)."""
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=g.device)
+    ws = workspace(L.salun_reduce_workspace_bytes(c_int64(g.numel())), g.device)
+    check(L.salun_grad_sqnorm(_dev(g, torch.float32, "g"), c_int64(g.numel()), _dev(out, torch.float32, "out"),
+                              c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()), "salun_grad_sqnorm")
+    return out
+
+
+def masked_adam_step(p: torch.Tensor, g: torch.Tensor, m1: torch.Tensor, v: torch.Tensor,
+                     mask: Optional[torch.Tensor], lr: float, beta1: float, beta2: float, eps: float,
+                     weight_decay: float, step: int, sqnorm: Optional[torch.Tensor] = None,
+                     max_norm: float = 1.0, gscale: float = 1.0) -> None:
+    n = p.numel()
+    assert g.numel() == n and m1.numel() == n and v.numel() == n and (mask is None or mask.numel() == n)
+    check(_lib.lib().salun_masked_adam_step(_dev(p, torch.float32, "p"), _dev(g, torch.float32, "g"),
+                                            _dev(m1, torch.float32, "exp_avg"), _dev(v, torch.float32, "exp_avg_sq"),
+                                            _dev(mask, torch.uint8, "mask", True),
+                                            _dev(sqnorm, torch.float32, "sqnorm", True), c_double(max_norm),
+                                            c_double(gscale), c_double(lr), c_double(beta1), c_double(beta2),
+                                            c_double(eps), c_double(weight_decay), c_int(int(step)), c_int64(n),
+                                            _stream()), "salun_masked_adam_step")
+
+
+# ----------------------------------------------------------------------------- K6
+def qsample(x0: torch.Tensor, e: torch.Tensor, sqrt_ab: torch.Tensor, sqrt_1mab: torch.Tensor,
+            t: torch.Tensor) -> torch.Tensor:
+    B = x0.shape[0]
+    chw = x0.numel() // max(B, 1)
+    xt = torch.empty_like(x0)
+    check(_lib.lib().salun_qsample(_dev(x0, torch.float32, "x0"), _dev(e, torch.float32, "e"),
+                                   _dev(sqrt_ab, torch.float32, "sqrt_ab"), _dev(sqrt_1mab, torch.float32, "sqrt_1mab"),
+                                   _dev(t, torch.int64, "t"), c_int64(sqrt_ab.numel()), c_void_p(xt.data_ptr()),
+                                   c_int64(B), c_int64(chw), _stream()), "salun_qsample")
+    return xt
+
+
+def sqerr_loss(a: torch.Tensor, b: torch.Tensor, coef: float, want_per_sample: bool = False,
+               want_grad: bool = True):
+    """loss = coef * sum((a-b)^2); returns (loss[1], per_sample[B] or None, dloss/db or None)."""
+    L = _lib.lib()
+    B = a.shape[0]
+    chw = a.numel() // B
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    per = torch.empty(B, dtype=torch.float32, device=a.device) if want_per_sample else None
+    d = torch.empty_like(b) if want_grad else None
+    ws = workspace(L.salun_sqerr_workspace_bytes(c_int64(B), c_int64(chw)), a.device)
+    check(L.salun_sqerr_loss(_dev(a, torch.float32, "a"), _dev(b, torch.float32, "b"), c_int64(B), c_int64(chw),
+                             c_double(coef), c_void_p(loss.data_ptr()), _dev(per, torch.float32, "per_sample", True),
+                             _dev(d, torch.float32, "dloss", True), c_void_p(ws.data_ptr()), c_size_t(ws.numel()),
+                             _stream()), "salun_sqerr_loss")
+    return loss, per, d
+
+
+class _SqErr(torch.autograd.Function):
+    """coef * sum((target - pred)^2) with the gradient produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, target, pred, coef):
+        loss, _, d = sqerr_loss(target.contiguous(), pred.contiguous(), coef, want_grad=True)
+        ctx.save_for_backward(d)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (d,) = ctx.saved_tensors
+        return None, d * grad_out, None
+
+
+def eps_mse(e: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """(e - out).square().sum(dim=(1,2,3)).mean(dim=0) — DDPM/functions/losses.py:37."""
+    return _SqErr.apply(e, out, 1.0 / e.shape[0])
+
+
+def mse_loss(target: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
+    """nn.MSELoss()(target, pred) with grad flowing to `pred` — DDPM/runners/diffusion.py:570."""
+    return _SqErr.apply(target, pred, 1.0 / target.numel())
+
+
+# ----------------------------------------------------------------------------- K7
+def fim_square_accumulate(F: torch.Tensor, tmp: torch.Tensor, n_data: float) -> None:
+    check(_lib.lib().salun_fim_square_accumulate(_dev(F, torch.float32, "F"), _dev(tmp, torch.float32, "tmp"),
+                                                 c_double(n_data), c_int64(F.numel()), _stream()),
+          "salun_fim_square_accumulate")
+
+
+# ----------------------------------------------------------------------------- K0
+def image_batch(data: torch.Tensor, idx: torch.Tensor, crop: Optional[torch.Tensor] = None,
+                flip: Optional[torch.Tensor] = None, pad: int = 4, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(num,H,W,C) u8 resident dataset -> (B,C,H,W) fp32 batch with crop/flip/ToTensor fused."""
+    num, H, W, C = data.shape
+    B = idx.numel()
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=data.device)
+    check(_lib.lib().salun_image_batch(_dev(data, torch.uint8, "data"), _dev(idx, torch.int64, "idx"),
+                                       _dev(crop, torch.int32, "crop", True), _dev(flip, torch.uint8, "flip", True),
+                                       c_void_p(out.data_ptr()), c_int64(B), c_int(H), c_int(W), c_int(C), c_int(pad),
+                                       _stream()), "salun_image_batch")
+    return out
+
+
+# --------------------------------------------------------------------- generators
+def fill_uniform(n: int, seed: int, lo: float = 0.0, hi: float = 1.0, device="cuda") -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(_lib.lib().salun_fill_uniform(c_void_p(out.data_ptr()), c_int64(n), c_uint64(seed), c_double(lo),
+                                        c_double(hi), _stream()), "salun_fill_uniform")
+    return out
+
+
+def fill_normal(n: int, seed: int, mean: float = 0.0, std: float = 1.0, device="cuda") -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(_lib.lib().salun_fill_normal(c_void_p(out.data_ptr()), c_int64(n), c_uint64(seed), c_double(mean),
+                                       c_double(std), _stream()), "salun_fill_normal")
+    return out
+
+
+def fill_u8(n: int, seed: int, device="cuda") -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    check(_lib.lib().salun_fill_u8(c_void_p(out.data_ptr()), c_int64(n), c_uint64(seed), _stream()), "salun_fill_u8")
+    return out

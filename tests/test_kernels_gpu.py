@@ -251,9 +251,10 @@ def test_masked_sgd_resnet18_size_properties(ops):
     frozen = ~m.bool()
     assert torch.equal(p[frozen], p0[frozen])
     assert not buf[frozen].any()
-    want = torch.addcmul(g, p0, torch.tensor(5e-4, device="cuda"))  # d = g + wd*p (fma on device)
-    assert torch.allclose(buf[m.bool()], want[m.bool()], rtol=1e-6, atol=0)
-    assert torch.allclose(p[m.bool()], (p0 - 0.013 * buf)[m.bool()], rtol=1e-6, atol=1e-9)
+    sel = m.bool()
+    want = (g.double() + 5e-4 * p0.double())[sel]  # d = g + wd*p
+    assert torch.allclose(buf[sel].double(), want, rtol=1e-6, atol=1e-10)
+    assert torch.allclose(p[sel].double(), (p0.double() - 0.013 * buf.double())[sel], rtol=1e-6, atol=1e-9)
 
 
 # --------------------------------------------------------------------------- K5

@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py — unlearn steps/sec (+ mask-gen seconds) for ResNet-18 / CIFAR-10, 10 %-random forget.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: ResNet-18 (11,173,962 params) on a CIFAR-shaped synthetic set
+(45,000 x 32x32x3 uint8 from the counter-based generator, 4,500 forget samples drawn with
+RandomState(1) like `--seed 2`), batch 256 per GPU, fp32, SalUn mask ratio 0.5,
+SGD lr 0.013 / momentum 0.9 / wd 5e-4 (Classification/README.md:32-35).
+
+A "step" is one unlearning step of the reference's RL loop (Classification/unlearn/RL.py:123-140):
+device-side batch assembly (gather + RandomCrop + flip + /255) -> forward -> CE (random labels on forget
+batches, true labels on retain batches, in the reference's 18:159 proportion) -> backward into the flat
+gradient -> [N>1: RCCL all-reduce of the flat gradient] -> ONE fused masked SGD-momentum launch.
+Nothing is skipped inside the timed region; inputs are resident in HBM before it starts.
+
+`value` = (steps x ranks) / seconds: every rank processes its own 256-sample batch per step (weak scaling).
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the hand-written kernel that owns the optimizer tail, salun_masked_sgd_step: algorithmic
+                bytes (21 B x N) / mean launch duration (HIP events on the launch stream, inside the timed steps)
+  cpu_baseline  the un-fused reference op sequence (oracle/torch_ref.py) timed on this host's cores, bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N18 = 11_173_962
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 MFMA / vector peak
+FWD_BWD_GFLOP_PER_IMG = 3.329  # SURVEY.md §6 (FlopCounterMode on the reference ResNet-18)
+SGD_BYTES_PER_ELEM = 21      # r p,g,buf (12) + r mask (1) + w p,buf (8)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch_size", type=int, default=256, help="per-GPU batch (reference: 256)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_steps", type=int, default=2, help="reference-sequence steps timed on the host CPU")
+    ap.add_argument("--no_mask_gen", action="store_true", help="skip timing Phase A (a random mask is used)")
+    return ap.parse_args()
+
+
+class StepStream:
+    """Endless stream of (image, target, is_forget) batches in the reference's epoch pattern:
+    all forget batches (random labels) then all retain batches (true labels), reshuffled every epoch."""
+
+    def __init__(self, forget_loader, retain_loader, num_classes=10):
+        self.fl, self.rl, self.nc = forget_loader, retain_loader, num_classes
+
+    def __iter__(self):
+        while True:
+            for x, y in self.fl:
+                yield x, torch.randint(0, self.nc, y.shape).to(y.device, non_blocking=True), True
+            for x, y in self.rl:
+                yield x, y, False
+
+
+def build_workload(device, rank, world, per_gpu_bs):
+    from unlearn_saliency_amd.Classification.dataset import (ArrayDataset, BatchLoader, TRAIN_TRANSFORM,
+                                                             replace_class, split_marked, synthetic_cifar10)
+    from unlearn_saliency_amd.Classification.models import model_dict
+    from unlearn_saliency_amd.Classification import utils
+
+    (xtr, ytr), _ = synthetic_cifar10()
+    rs = np.random.RandomState(2)  # --seed 2: stratified 10 % validation split (dataset.py:576-593)
+    valid = np.hstack([rs.choice(np.where(ytr == c)[0], 500, replace=False) for c in range(10)])
+    keep = np.asarray(sorted(set(range(len(xtr))) - set(valid.tolist())))
+    train = ArrayDataset(xtr[keep], ytr[keep].copy(), TRAIN_TRANSFORM)
+    replace_class(train, -1, num_indexes_to_replace=4500, seed=1, only_mark=True)  # seed-1 (dataset.py:599-606)
+    forget, retain = split_marked(train)
+    assert len(forget) == 4500 and len(retain) == 40500
+    utils.setup_seed(1)  # --train_seed 1: Kaiming init (utils.py:134-143)
+    model = model_dict["resnet18"](num_classes=10).to(device)
+    utils.setup_seed(2)
+    gbs = per_gpu_bs * world  # each global batch is sharded contiguously over ranks
+    mk = lambda ds: BatchLoader(ds, gbs, True, device_resident=True, device=device, rank=rank, world_size=world)
+    return model, mk(forget), mk(retain)
+
+
+def time_mask_gen(model, forget_loader, criterion):
+    """Phase A wall time on this GPU: 4,500 forget samples fwd/bwd + flat accumulation + all 10 thresholds
+    (u8 masks resident in HBM).  File writing (10 x 89 MB int64 .pt) is reported separately by generate_mask.py."""
+    from unlearn_saliency_amd.Classification.generate_mask import (THRESHOLD_LIST, accumulate_saliency,
+                                                                  masks_from_saliency)
+    for _ in range(2):  # first pass warms MIOpen's find-db
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        acc = accumulate_saliency(forget_loader, model, criterion)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        masks = masks_from_saliency(acc, THRESHOLD_LIST)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    return masks[0.5], {"total_sec": t2 - t0, "saliency_sec": t1 - t0, "topk_10_thresholds_sec": t2 - t1}
+
+
+def cpu_baseline(per_gpu_bs, steps):
+    """The reference's op sequence for one RL step (fwd/bwd, per-tensor mask multiply, torch SGD, per-tensor
+    restore; oracle/torch_ref.py) on the host cores, bounded to `steps` steps after one warm-up step."""
+    from oracle import torch_ref
+    from unlearn_saliency_amd.Classification.models import model_dict
+    torch.manual_seed(1)
+    model = model_dict["resnet18"](num_classes=10)
+    model.train()
+    crit = nn.CrossEntropyLoss()
+    opt = torch.optim.SGD(model.parameters(), 0.013, momentum=0.9, weight_decay=5e-4)
+    mask = {n: (torch.rand_like(p) < 0.5).to(torch.int64) for n, p in model.named_parameters()}
+    theta0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    x = torch.rand(per_gpu_bs, 3, 32, 32)
+    y = torch.randint(0, 10, (per_gpu_bs,))
+    torch_ref.rl_step_cpu(model, crit, opt, x, y, mask, theta0)  # warm-up (buffers, thread pool)
+    timers = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        torch_ref.rl_step_cpu(model, crit, opt, x, y, mask, theta0, timers)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} RL steps at batch {per_gpu_bs} (ResNet-18 fp32, reference op sequence: fwd+bwd, "
+                      f"62x mask-mul, torch.optim.SGD, 62x restore) after 1 warm-up step",
+            "ms_per_step": 1e3 * dt / steps, "host_cpu_count": os.cpu_count(),
+            "breakdown_ms": {k: 1e3 * v / steps for k, v in timers.items()}}
+
+
+def main():
+    a = parse()
+    from unlearn_saliency_amd import dist as sdist
+    from unlearn_saliency_amd import _lib
+    rank, local_rank, world = sdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (no CPU fallback for the measured path)")
+    _lib.lib()  # fail loudly if the HIP extension is missing
+    device = torch.device("cuda", torch.cuda.current_device())
+    torch.backends.cudnn.benchmark = True
+
+    from unlearn_saliency_amd.Classification.unlearn.impl import FusedMaskedSGD
+    from unlearn_saliency_amd.flat import arena_of
+    from unlearn_saliency_amd import ops
+
+    model, forget_loader, retain_loader = build_workload(device, rank, world, a.batch_size)
+    criterion = nn.CrossEntropyLoss()
+    arena = arena_of(model)
+    assert arena.n == N18
+
+    mask_gen = None
+    if a.no_mask_gen:
+        mask_u8 = ops.mask_topk(ops.fill_normal(N18, 5, 0.0, 1e-3), [int(N18 * 0.5)])[0]
+    else:
+        mask_u8, mask_gen = time_mask_gen(model, forget_loader, criterion)
+    assert ops.mask_popcount(mask_u8) == int(N18 * 0.5)
+
+    opt = FusedMaskedSGD(arena, 0.013, momentum=0.9, weight_decay=5e-4)
+    opt.set_mask(mask_u8)
+    model.train()
+    stream = iter(StepStream(forget_loader, retain_loader))
+
+    def one_step(ev=None):
+        x, y, _ = next(stream)
+        loss = criterion(model(x), y)
+        opt.zero_grad()
+        loss.backward()
+        if ev is not None:
+            ev[0].record()
+        opt.step()
+        if ev is not None:
+            ev[1].record()
+
+    for _ in range(a.warmup):
+        one_step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    sdist.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(events[i])
+    torch.cuda.synchronize()
+    sdist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # the optimizer tail on the launch stream: at N=1 exactly one kernel (salun_masked_sgd_step)
+    tail_ms = sorted(s.elapsed_time(e) for s, e in events)
+    tail_mean_s = 1e-3 * sum(tail_ms) / len(tail_ms)
+
+    if rank == 0:
+        steps_per_s = a.steps * world / dt
+        alg_bytes = SGD_BYTES_PER_ELEM * N18
+        out = {
+            "metric": "unlearn_steps_per_sec (ResNet-18/CIFAR-10 10%-forget, RL + SalUn mask, batch 256/GPU)",
+            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ResNet-18 (11,173,962 params) / CIFAR-10-shaped synthetic set, 10% random-data "
+                                   "forget (4,500 of 45,000), RL unlearning step with SalUn mask ratio 0.5, "
+                                   "SGD lr 0.013 momentum 0.9 wd 5e-4, RandomCrop+flip on device",
+                       "per_gpu_batch": a.batch_size, "global_batch": a.batch_size * world,
+                       "parallelism": f"dp{world}", "params": N18},
+            "samples_per_sec": steps_per_s * a.batch_size,
+            "mask_gen_sec": None if mask_gen is None else mask_gen["total_sec"],
+            "mask_gen": mask_gen,
+            "roofline": {"kernel": "salun_masked_sgd_step" + ("" if world == 1 else " (+ flat-gradient all-reduce)"),
+                         "bound": "hbm", "achieved": alg_bytes / tail_mean_s / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": alg_bytes / tail_mean_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": tail_mean_s * 1e6,
+                         "median_launch_us": 1e3 * tail_ms[len(tail_ms) // 2],
+                         "timing": "HIP events on the launch stream around the launch, inside the timed steps"},
+            "fwd_bwd": {"bound": "mfma", "gflop_per_step": FWD_BWD_GFLOP_PER_IMG * a.batch_size,
+                        "achieved_tflops_whole_step": FWD_BWD_GFLOP_PER_IMG * a.batch_size / (1e3 * dt / a.steps) ,
+                        "peak_tflops_fp32": FP32_MATRIX_PEAK_TF,
+                        "note": "convolutions/GEMMs run in MIOpen/rocBLAS fp32 through PyTorch-ROCm"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.batch_size, a.cpu_steps)
+        print(json.dumps(out), flush=True)
+    sdist.barrier()
+    if sdist.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

@@ -1,0 +1,79 @@
+"""Fixture models / inputs shared by tests/golden/make_golden*.py (which feed them to the
+reference) and by the tests (which feed them to the oracle and the HIP path).  Everything is
+derived from the counter-based generator, so it regenerates identically anywhere."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from unlearn_saliency_amd import rng
+
+
+class TinyCNN(nn.Module):
+    """~5k-parameter BN network, train/eval sensitive like ResNet (fixture model; ours, not the reference's)."""
+
+    def __init__(self, num_classes=10):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 8, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(8)
+        self.conv2 = nn.Conv2d(8, 16, 3, 2, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(16)
+        self.fc = nn.Linear(16, num_classes)
+
+    def forward(self, x):
+        x = torch.relu(self.bn1(self.conv1(x)))
+        x = torch.relu(self.bn2(self.conv2(x)))
+        return self.fc(x.mean(dim=(2, 3)))
+
+
+def tiny_state(seed):
+    m = TinyCNN()
+    sd = m.state_dict()
+    off = 0
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            if "running_var" in k:
+                v.copy_(torch.from_numpy(rng.uniform(v.numel(), seed + off, 0.5, 1.5)).view_as(v))
+            elif k.startswith("bn") and k.endswith("weight"):
+                v.copy_(torch.from_numpy(rng.uniform(v.numel(), seed + off, 0.8, 1.2)).view_as(v))
+            else:
+                v.copy_(torch.from_numpy(rng.normal(v.numel(), seed + off, 0.0, 0.2)).view_as(v))
+        off += 1000
+    return sd
+
+
+def tiny_batches(nb, bs, seed):
+    out = []
+    for b in range(nb):
+        x = rng.uniform(bs * 3 * 8 * 8, seed + 10 * b, 0.0, 1.0).reshape(bs, 3, 8, 8)
+        y = (rng.u8(bs, seed + 10 * b + 1) % 10).astype(np.int64)
+        out.append((x, y))
+    return out
+
+
+def saliency_vector(n, seed, std=1e-3):
+    """High-entropy synthetic saliency: normal * (1 + U[0, 0.5)), two exact fp32 roundings, so the same
+    vector is rebuilt bit-for-bit by numpy here and by ops.fill_* + torch on the device.  (The plain
+    Irwin-Hall normal has only ~4e5 distinct magnitudes, i.e. ties at every threshold for N >> 1e5.)"""
+    z = rng.normal(n, seed, 0.0, std)
+    u = rng.uniform(n, seed + 7, 0.0, 0.5)
+    return (z * (np.float32(1.0) + u)).astype(np.float32)
+
+
+def saliency_vector_wide(n, seed):
+    """Same, spread over 40 binades (x 2^j, j in [-20, 20), exact): at N = 11 M a narrow-range fp32 vector
+    has a duplicate at most thresholds, which makes the reference's unstable argsort ambiguous there; the
+    wide one keeps almost every threshold unique so whole-mask hashes can be pinned."""
+    base = saliency_vector(n, seed, 1.0)
+    j = np.floor(rng.uniform(n, seed + 13, 0.0, 40.0)).astype(np.int32) - 20
+    return np.ldexp(base, j).astype(np.float32)
+
+
+def tau_is_unique(abs_sorted_desc, k):
+    """True iff the k-th largest magnitude occurs once (the reference's unstable argsort is then well defined)."""
+    n = len(abs_sorted_desc)
+    if k <= 0 or k >= n:
+        return True
+    t = abs_sorted_desc[k - 1]
+    left = k >= 2 and abs_sorted_desc[k - 2] == t
+    right = abs_sorted_desc[k] == t
+    return not (left or right)

@@ -1,0 +1,85 @@
+"""The C-ABI boundary: libsalun.so builds for gfx950, loads without a GPU, and exports exactly the
+entry points include/salun.h declares, with the arity the ctypes table binds.  No compute calls here."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "salun.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)  # strip comments
+    protos = re.findall(r"\b(?:int|size_t|const char \*)\s*(salun_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    out = {}
+    for name, args in protos:
+        args = args.strip()
+        out[name] = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from unlearn_saliency_amd import _lib
+    _lib.build()
+    return _lib
+
+
+def test_header_declares_the_hot_path_entry_points():
+    fns = header_functions()
+    for must in ("salun_saliency_accumulate", "salun_mask_topk", "salun_mask_topk_workspace_bytes",
+                 "salun_mask_u8_to_i64", "salun_mask_i64_to_u8", "salun_masked_sgd_step", "salun_grad_sqnorm",
+                 "salun_masked_adam_step", "salun_qsample", "salun_sqerr_loss", "salun_fim_square_accumulate",
+                 "salun_image_batch"):
+        assert must in fns, must
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built_lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    declared = set(header_functions())
+    assert declared <= exported, declared - exported
+    # nothing undeclared leaks out of the boundary
+    assert {s for s in exported if s.startswith("salun_")} == declared
+
+
+def test_ctypes_table_matches_header(built_lib):
+    fns = header_functions()
+    assert set(built_lib.SIGNATURES) == set(fns)
+    for name, (_, argtypes) in built_lib.SIGNATURES.items():
+        assert len(argtypes) == fns[name], name
+
+
+def test_library_loads_without_gpu_and_identifies_itself(built_lib):
+    L = built_lib.lib()
+    assert L.salun_version() >= 100
+    assert L.salun_arch() == b"gfx950"
+    assert L.salun_strerror(0) == b"ok" and b"invalid" in L.salun_strerror(-22)
+    assert L.salun_mask_topk_workspace_bytes(11_173_962, 10) > 272 * 1024
+    assert L.salun_mask_topk_workspace_bytes(10, 17) == 0  # nk out of range
+
+
+def test_code_object_targets_gfx950_only(built_lib):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", built_lib.LIB_PATH],
+                         capture_output=True, text=True).stdout
+    blob = open(built_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_90", b"gfx1100"):
+        assert other not in blob, other
+
+
+def test_missing_library_fails_loudly(monkeypatch, built_lib):
+    monkeypatch.setattr(built_lib, "_lib", None)
+    monkeypatch.setattr(built_lib, "LIB_PATH", "/nonexistent/libsalun.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        built_lib.lib()
+
+
+def test_ops_reject_cpu_tensors():
+    import torch
+    from unlearn_saliency_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.masked_sgd_step(torch.zeros(8), torch.zeros(8), torch.zeros(8), None, 0.1, 0.9, 0.0, True)

@@ -1,0 +1,48 @@
+"""Repository rules the judge checks mechanically: the product never touches oracle/, the oracle
+declares itself test infrastructure, no reference sources under tests/, run-time code never reads
+/root/reference."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "unlearn_saliency_amd")
+
+
+def _py_files(top):
+    for d, _, fs in os.walk(top):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".c")):
+                yield os.path.join(d, f)
+
+
+def test_product_never_imports_or_links_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|liboracle|import_module\([\"']oracle|CDLL\([^)]*oracle", re.M)
+    for path in _py_files(PKG):
+        assert not pat.search(open(path).read()), path
+
+
+def test_oracle_header_says_test_infrastructure():
+    assert "TEST INFRASTRUCTURE ONLY" in open(os.path.join(ROOT, "oracle", "salun_oracle.c")).read()
+    assert "TEST INFRASTRUCTURE ONLY" in open(os.path.join(ROOT, "oracle", "__init__.py")).read()
+
+
+def test_runtime_code_never_reads_the_reference_checkout():
+    allowed = {os.path.join(ROOT, "tests", "golden", n) for n in os.listdir(os.path.join(ROOT, "tests", "golden"))
+               if n.startswith("make_golden")}
+    allowed.add(os.path.abspath(__file__))
+    for top in (PKG, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        for path in _py_files(top):
+            if path in allowed:
+                continue
+            assert "/root/reference" not in open(path).read(), path
+    for f in ("bench.py", "__graft_entry__.py"):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            src = open(p).read()
+            # build() may compile oracle/_ref when the checkout exists; nothing else may mention it
+            assert src.count("/root/reference") <= 2, f
+
+
+def test_no_cpu_fallback_in_ops():
+    src = open(os.path.join(PKG, "ops.py")).read()
+    assert "no CPU fallback" in src and ".cpu()" not in src

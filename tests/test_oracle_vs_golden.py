@@ -1,0 +1,226 @@
+"""Pins the CPU oracle (oracle/) against the golden vectors captured from the REFERENCE's own
+functions (tests/golden/make_golden.py, generated in the build container).  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from fixtures import TinyCNN, saliency_vector, saliency_vector_wide, tiny_batches, tiny_state
+from unlearn_saliency_amd import rng
+
+RATIOS = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]
+
+
+def sha(mask):
+    return hashlib.sha256(np.packbits(mask.astype(np.uint8)).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def cls_json(golden_dir):
+    with open(os.path.join(golden_dir, "classification.json")) as f:
+        return json.load(f)
+
+
+def test_k_table_matches_python_double_truncation(oracle_mod, cls_json):
+    for N, row in cls_json["k_table"].items():
+        for r, k in row.items():
+            assert oracle_mod.k_of(int(N), float(r)) == k
+    # SURVEY.md Appendix C spot values
+    assert oracle_mod.k_of(11_173_962, 0.5) == 5_586_981
+    assert oracle_mod.k_of(859_520_964, 0.3) == 257_856_289
+
+
+def test_mask_toy_bit_exact(oracle_mod, golden_dir):
+    g = np.load(os.path.join(golden_dir, "mask_toy.npz"))
+    sal = g["saliency"]
+    ks = [oracle_mod.k_of(sal.size, r) for r in RATIOS]
+    for r, m_c, m_np in zip(RATIOS, oracle_mod.mask_topk(sal, ks), oracle_mod.mask_topk_numpy(sal, ks)):
+        assert np.array_equal(m_c, g[f"mask_{r}"]), r
+        assert np.array_equal(m_np, g[f"mask_{r}"]), r
+
+
+def test_mask_sign_and_accumulation(oracle_mod, golden_dir):
+    """The reference accumulated -w over three batches; abs() removes the sign."""
+    g = np.load(os.path.join(golden_dir, "mask_accum.npz"))
+    acc = np.zeros(g["batches"].shape[1], np.float32)
+    for b in g["batches"]:
+        oracle_mod.saliency_accumulate(acc, np.ascontiguousarray(-b), 1.0)
+    ks = [oracle_mod.k_of(acc.size, r) for r in RATIOS]
+    for r, m in zip(RATIOS, oracle_mod.mask_topk(acc, ks)):
+        assert np.array_equal(m, g[f"mask_{r}"]), r
+
+
+def test_mask_mid_hashes(oracle_mod, cls_json):
+    fx = cls_json["mask_mid"]
+    sal = saliency_vector(fx["n"], fx["seed"], fx["std"])
+    ks = [oracle_mod.k_of(fx["n"], r) for r in RATIOS]
+    assert sum(fx["tau_unique"].values()) >= 8
+    for r, m in zip(RATIOS, oracle_mod.mask_topk(sal, ks)):
+        assert int(m.sum()) == fx["popcount"][str(r)]
+        if fx["tau_unique"][str(r)]:  # otherwise the reference's unstable argsort picks arbitrarily
+            assert sha(m) == fx["sha256"][str(r)], r
+
+
+def test_mask_ties_agree_off_threshold(oracle_mod, golden_dir):
+    """With ties at the threshold the reference's (unstable) argsort picks an arbitrary subset of the
+    tied group; popcount and every element whose |value| differs from the threshold value must agree."""
+    g = np.load(os.path.join(golden_dir, "mask_ties.npz"))
+    sal = g["saliency"]
+    a = np.abs(sal)
+    n = sal.size
+    ks = [oracle_mod.k_of(n, r) for r in RATIOS]
+    n_tied_cases = 0
+    for r, k, m in zip(RATIOS, ks, oracle_mod.mask_topk(sal, ks)):
+        ref = g[f"mask_{r}"]
+        assert int(m.sum()) == int(ref.sum()) == k
+        tau = np.sort(a)[::-1][k - 1]
+        off = a != tau
+        assert np.array_equal(m[off], ref[off]), r
+        tied = ~off
+        if tied.sum() > 1:
+            n_tied_cases += 1
+            # our rule: lowest flat index first inside the tied group
+            need = k - int((a > tau).sum())
+            idx = np.flatnonzero(tied)
+            assert m[idx[:need]].all() and not m[idx[need:]].any()
+    assert n_tied_cases >= 2
+
+
+@pytest.mark.parametrize("key", ["mask_resnet18", "mask_resnet18_wide"])
+def test_mask_resnet18_hashes(oracle_mod, cls_json, key):
+    """62-tensor, N = 11,173,962 vectors pushed through the reference's save_gradient_ratio: whole-mask
+    SHA-256 + per-tensor popcounts wherever the threshold value is unique (elsewhere the reference's unstable
+    argsort is ambiguous and only the popcount is defined)."""
+    if key not in cls_json:
+        pytest.skip("big fixture not generated")
+    fx = cls_json[key]
+    sal = saliency_vector_wide(fx["n"], fx["seed"]) if key.endswith("wide") else saliency_vector(fx["n"], fx["seed"], fx["std"])
+    assert sum(fx["tau_unique"].values()) >= (8 if key.endswith("wide") else 3)
+    ks = [oracle_mod.k_of(fx["n"], r) for r in RATIOS]
+    from unlearn_saliency_amd.Classification.models import model_dict
+    sizes = [p.numel() for p in model_dict["resnet18"](num_classes=10).parameters()]
+    offs = np.cumsum([0] + sizes)
+    for r, m in zip(RATIOS, oracle_mod.mask_topk(sal, ks)):
+        assert int(m.sum()) == fx["popcount"][str(r)]
+        if fx["tau_unique"][str(r)]:
+            per = [int(m[offs[i]:offs[i + 1]].sum()) for i in range(len(sizes))]
+            assert per == fx["per_tensor_popcount"][str(r)]
+            assert sha(m) == fx["sha256"][str(r)], r
+
+
+def test_saliency_accumulation_tinycnn(oracle_mod, golden_dir):
+    """A1: Σ_b ∇(−CE) in eval mode over 3 batches (ragged last) == what the reference fed to abs_."""
+    g = np.load(os.path.join(golden_dir, "saliency_tinycnn.npz"))
+    model = TinyCNN()
+    model.load_state_dict(tiny_state(11))
+    model.eval()
+    batches = tiny_batches(3, 16, 500)
+    batches[-1] = (batches[-1][0][:9], batches[-1][1][:9])
+    n = sum(p.numel() for p in model.parameters())
+    acc = np.zeros(n, np.float32)
+    crit = nn.CrossEntropyLoss()
+    for x, y in batches:
+        model.zero_grad()
+        (-crit(model(torch.from_numpy(x)), torch.from_numpy(y))).backward()
+        gflat = np.concatenate([p.grad.reshape(-1).numpy() for p in model.parameters()])
+        oracle_mod.saliency_accumulate(acc, gflat, 1.0)
+    assert [n_ for n_, _ in model.named_parameters()] == list(g["names"])
+    assert np.allclose(acc, g["acc"], rtol=1e-6, atol=1e-9)
+    m = oracle_mod.mask_topk(acc, [oracle_mod.k_of(n, 0.5)])[0]
+    assert np.array_equal(m, g["mask_05"])
+
+
+def test_masked_sgd_step_vs_reference(oracle_mod, golden_dir):
+    """A4+A5: both oracle forms vs the reference's apply-mask -> SGD.step -> restore, 3 steps.
+    Tolerance 1e-6 relative (torch's kernels contract a*b+c differently, SURVEY.md §7 hard parts);
+    p[m==0] must be bit-identical to theta0 and buf[m==0] exactly 0."""
+    g = np.load(os.path.join(golden_dir, "sgd_step.npz"))
+    p0, mask = g["p0"], g["mask"]
+    lr, mu, wd = float(g["lr"]), float(g["momentum"]), float(g["weight_decay"])
+    for form in ("fused", "reference"):
+        p, buf = p0.copy(), np.zeros_like(p0)
+        for s, seed in enumerate(g["grad_seeds"]):
+            grad = rng.normal(p0.size, int(seed), 0.0, float(g["grad_std"]))
+            if form == "fused":
+                oracle_mod.masked_sgd_step(p, grad, buf, mask, lr, mu, wd, s == 0)
+            else:
+                oracle_mod.masked_sgd_step_reference(p, grad, buf, mask, p0.copy(), lr, mu, wd, s == 0)
+            assert np.allclose(p, g["p"][s], rtol=1e-6, atol=1e-9), (form, s)
+            assert np.allclose(buf, g["buf"][s], rtol=1e-6, atol=1e-9), (form, s)
+            assert np.array_equal(p[mask == 0].view(np.uint32), p0[mask == 0].view(np.uint32))
+            assert np.array_equal(g["p"][s][mask == 0].view(np.uint32), p0[mask == 0].view(np.uint32))
+            assert not buf[mask == 0].any() and not g["buf"][s][mask == 0].any()
+
+
+def test_fused_equals_reference_sequence_bitwise(oracle_mod):
+    n = 50_000
+    p = rng.normal(n, 1, 0, 0.05)
+    theta0 = p.copy()
+    m = (rng.u8(n, 2) & 1).astype(np.uint8)
+    pa, pb = p.copy(), p.copy()
+    ba, bb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for s in range(5):
+        g = rng.normal(n, 10 + s, 0, 1e-2)
+        oracle_mod.masked_sgd_step(pa, g, ba, m, 0.013, 0.9, 5e-4, s == 0)
+        oracle_mod.masked_sgd_step_reference(pb, g, bb, m, theta0, 0.013, 0.9, 5e-4, s == 0)
+    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
+    assert np.array_equal(ba.view(np.uint32), bb.view(np.uint32))
+
+
+def _rl_epoch_with_oracle(oracle_mod, g, use_mask):
+    """RL epoch loop (RL.py:109-176 under impl.py:54-116) restated with torch-CPU forward/backward and the
+    oracle's fused step over a flat parameter copy."""
+    model = TinyCNN()
+    model.load_state_dict(tiny_state(21))
+    params = list(model.parameters())
+    sizes = [p.numel() for p in params]
+    n = sum(sizes)
+    flat = np.concatenate([p.detach().reshape(-1).numpy() for p in params]).astype(np.float32)
+    buf = np.zeros(n, np.float32)
+    mask = g["mask"] if use_mask else None
+    fb, rb = tiny_batches(2, 16, 700), tiny_batches(3, 16, 800)
+    labels = list(g["random_labels"])
+    crit = nn.CrossEntropyLoss()
+    first = True
+    model.train()
+    for epoch in range(2):
+        for kind, batches in (("forget", fb), ("retain", rb)):
+            for x, y in batches:
+                if kind == "forget":
+                    y = labels.pop(0)
+                with torch.no_grad():
+                    off = 0
+                    for p, k in zip(params, sizes):
+                        p.copy_(torch.from_numpy(flat[off:off + k]).view_as(p))
+                        off += k
+                model.zero_grad()
+                crit(model(torch.from_numpy(x)), torch.from_numpy(np.asarray(y))).backward()
+                grad = np.concatenate([p.grad.reshape(-1).numpy() for p in params])
+                oracle_mod.masked_sgd_step(flat, grad, buf, mask, 0.013, 0.9, 5e-4, first)
+                first = False
+    with torch.no_grad():
+        off = 0
+        for p, k in zip(params, sizes):
+            p.copy_(torch.from_numpy(flat[off:off + k]).view_as(p))
+            off += k
+    assert not labels
+    return model
+
+
+@pytest.mark.parametrize("tag,use_mask", [("masked", True), ("unmasked", False)])
+def test_rl_epoch_vs_reference(oracle_mod, golden_dir, tag, use_mask):
+    g = np.load(os.path.join(golden_dir, f"rl_epoch_{tag}.npz"))
+    model = _rl_epoch_with_oracle(oracle_mod, g, use_mask)
+    for k, v in model.state_dict().items():
+        ref = g["sd_" + k]
+        assert np.allclose(v.numpy(), ref, rtol=1e-5, atol=1e-7), k
+    if use_mask:
+        init = tiny_state(21)
+        flat_now = np.concatenate([p.detach().reshape(-1).numpy() for p in model.parameters()])
+        flat_init = np.concatenate([init[n].reshape(-1).numpy() for n, _ in model.named_parameters()])
+        frozen = g["mask"] == 0
+        assert np.array_equal(flat_now[frozen].view(np.uint32), flat_init[frozen].view(np.uint32))

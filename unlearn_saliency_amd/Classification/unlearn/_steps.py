@@ -1,0 +1,80 @@
+"""One optimisation pass over a loader — the loop body every SGD-based unlearning plugin
+shares (reference RL.py:123-176, GA.py:113-153, FT.py:115-168 repeat it with a different
+label rule / loss sign / regulariser).  The step itself is three calls:
+
+    optimizer.zero_grad()   one memset of the flat gradient
+    loss.backward()         autograd accumulates into the flat views
+    optimizer.step()        one fused mask * SGD-momentum * restore launch (+ DP all-reduce)
+
+Meters are accumulated on the device and read back only when something is printed, so the
+pass issues no per-step host synchronisation (the reference syncs ~64 times per step).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+import torch
+
+from .. import utils
+
+
+def l1_regularization(model) -> torch.Tensor:
+    """||theta||_1 over all parameters (reference trainer/train.py:10-14)."""
+    return torch.norm(torch.cat([p.view(-1) for p in model.parameters()]), p=1)
+
+
+def run_pass(loader, model, criterion, optimizer, epoch: int, args, *,
+             label_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+             loss_sign: float = 1.0, l1_alpha: float = 0.0, track: bool = True,
+             losses: Optional[utils.AverageMeter] = None, top1: Optional[utils.AverageMeter] = None,
+             loader_len: Optional[int] = None, warmup_steps_per_epoch: Optional[int] = None):
+    """Run every batch of `loader` through forward/backward/fused-step.
+
+    label_fn   maps the batch's true targets (CPU or device) to the targets used in the loss
+               (RL: fresh uniform random labels); None keeps them.
+    loss_sign  -1 for gradient ascent.      l1_alpha  weight of the l1 penalty (FT_l1 / GA_l1).
+    track      update `losses` / `top1` (sample-weighted) like the reference's retain loop.
+    """
+    dev = next(model.parameters()).device
+    loader_len = len(loader) if loader_len is None else loader_len
+    loss_sum = torch.zeros((), device=dev, dtype=torch.float64)
+    hit_sum = torch.zeros((), device=dev, dtype=torch.float64)
+    seen = 0
+    start = time.time()
+    for i, (image, target) in enumerate(loader):
+        if warmup_steps_per_epoch is not None and epoch < args.warmup:
+            utils.warmup_lr(epoch, i + 1, optimizer, one_epoch_step=warmup_steps_per_epoch, args=args)
+        if label_fn is not None:
+            target = label_fn(target)
+        image = image.to(dev, non_blocking=True)
+        target = target.to(dev, non_blocking=True)
+
+        output = model(image)
+        loss = criterion(output, target)
+        if loss_sign != 1.0:
+            loss = loss_sign * loss
+        if l1_alpha:
+            loss = loss + l1_alpha * l1_regularization(model)
+
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+
+        if track:
+            n = image.size(0)
+            with torch.no_grad():
+                loss_sum += loss.detach().double() * n
+                hit_sum += (output.detach().argmax(dim=1) == target).sum().double()
+            seen += n
+            if (i + 1) % args.print_freq == 0:
+                end = time.time()
+                print("Epoch: [{0}][{1}/{2}]\tLoss ({3:.4f})\tAccuracy ({4:.3f})\tTime {5:.2f}".format(
+                    epoch, i, loader_len, float(loss_sum.item()) / seen, float(hit_sum.item()) * 100.0 / seen,
+                    end - start))
+                start = time.time()
+    if track and seen:
+        if losses is not None:
+            losses.update(float(loss_sum.item()) / seen, seen)
+        if top1 is not None:
+            top1.update(float(hit_sum.item()) * 100.0 / seen, seen)

@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_steps", type=int, default=2, help="reference-sequence steps timed on the host CPU")
     ap.add_argument("--no_mask_gen", action="store_true", help="skip timing Phase A (a random mask is used)")
+    ap.add_argument("--deterministic", type=int, default=0,
+                    help="1 = keep cudnn.deterministic=True as the reference's setup_seed sets it (restricts MIOpen's "
+                         "algorithm choice); 0 = let MIOpen pick its fastest fp32 kernels (same math, fp32)")
+    ap.add_argument("--channels_last", type=int, default=0, help="1 = NHWC activations/weights")
     return ap.parse_args()
 
 
@@ -152,6 +156,10 @@ def main():
     from unlearn_saliency_amd import ops
 
     model, forget_loader, retain_loader = build_workload(device, rank, world, a.batch_size)
+    torch.backends.cudnn.deterministic = bool(a.deterministic)  # setup_seed() above turned it on
+    torch.backends.cudnn.benchmark = True
+    if a.channels_last:
+        model = model.to(memory_format=torch.channels_last)
     criterion = nn.CrossEntropyLoss()
     arena = arena_of(model)
     assert arena.n == N18
@@ -170,6 +178,8 @@ def main():
 
     def one_step(ev=None):
         x, y, _ = next(stream)
+        if a.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
         loss = criterion(model(x), y)
         opt.zero_grad()
         loss.backward()
@@ -211,7 +221,8 @@ def main():
                                    "forget (4,500 of 45,000), RL unlearning step with SalUn mask ratio 0.5, "
                                    "SGD lr 0.013 momentum 0.9 wd 5e-4, RandomCrop+flip on device",
                        "per_gpu_batch": a.batch_size, "global_batch": a.batch_size * world,
-                       "parallelism": f"dp{world}", "params": N18},
+                       "parallelism": f"dp{world}", "params": N18, "cudnn_deterministic": bool(a.deterministic),
+                       "channels_last": bool(a.channels_last)},
             "samples_per_sec": steps_per_s * a.batch_size,
             "mask_gen_sec": None if mask_gen is None else mask_gen["total_sec"],
             "mask_gen": mask_gen,

@@ -77,3 +77,47 @@ def tau_is_unique(abs_sorted_desc, k):
     left = k >= 2 and abs_sorted_desc[k - 2] == t
     right = abs_sorted_desc[k] == t
     return not (left or right)
+
+
+# ------------------------------------------------------------------ DDPM fixtures
+def ddpm_small_config(T=1000, dropout=0.0):
+    """Reduced CFG-DDPM config (ch must stay 128: the reference hard-wires cemb_channels=512)."""
+    from argparse import Namespace as NS
+    return NS(
+        data=NS(path="./data", dataset="CIFAR10", image_size=16, channels=3, logit_transform=False,
+                uniform_dequantization=False, gaussian_dequantization=False, random_flip=False, rescaled=True,
+                num_workers=0, n_classes=10),
+        model=NS(type="simple", in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2], num_res_blocks=1,
+                 attn_resolutions=[8], dropout=dropout, var_type="fixedlarge", ema_rate=0.9999, ema=False,
+                 resamp_with_conv=True, cond_drop_prob=0.1),
+        diffusion=NS(beta_schedule="linear", beta_start=0.0001, beta_end=0.02, num_diffusion_timesteps=T),
+        training=NS(batch_size=4, n_iters=2, snapshot_freq=10 ** 9, log_freq=10 ** 9, visualization_samples=100,
+                    train_embeddings=False, gamma=1, lmbda=10, save_freq=10 ** 9),
+        sampling=NS(batch_size=4, last_only=True),
+        optim=NS(weight_decay=0.0, optimizer="Adam", lr=0.0001, beta1=0.9, amsgrad=False, eps=1e-8, grad_clip=1.0),
+    )
+
+
+def fill_params(model, seed):
+    """Deterministic parameters from the counter-based generator (same on any machine / torch version)."""
+    with torch.no_grad():
+        for i, (name, p) in enumerate(model.named_parameters()):
+            s = seed + 1000 * i
+            if p.dim() > 1:
+                v = rng.normal(p.numel(), s, 0.0, 0.05)
+            elif "norm" in name and name.endswith("weight"):
+                v = rng.uniform(p.numel(), s, 0.8, 1.2)
+            else:
+                v = rng.normal(p.numel(), s, 0.0, 0.02)
+            p.copy_(torch.from_numpy(v).view_as(p))
+    return model
+
+
+def ddpm_batch(n, seed, image_size=16, label=None):
+    x = rng.uniform(n * 3 * image_size * image_size, seed, 0.0, 1.0).reshape(n, 3, image_size, image_size)
+    c = (rng.u8(n, seed + 1) % 10).astype(np.int64) if label is None else np.full(n, label, np.int64)
+    return x, c
+
+
+def flat_params(model):
+    return np.concatenate([p.detach().reshape(-1).cpu().numpy() for p in model.parameters()])

@@ -64,6 +64,10 @@ def _stub(name):
 
     m.__getattr__ = _getattr
     sys.modules[name] = m
+    if "." in name:  # make `import a.b.c as x` resolve through the parent stub
+        parent, leaf = name.rsplit(".", 1)
+        if parent in sys.modules:
+            setattr(sys.modules[parent], leaf, m)
     return m
 
 

@@ -87,7 +87,8 @@ def test_save_gradient_ratio_matches_reference_golden(golden_dir):
     batches[-1] = (batches[-1][0][:9], batches[-1][1][:9])
     loaders = {"forget": _loader(batches)}
     acc = gm.accumulate_saliency(loaders["forget"], model, nn.CrossEntropyLoss())
-    assert np.allclose(acc.cpu().numpy(), g["acc"], rtol=1e-5, atol=1e-8)
+    # 1e-5 relative to the vector's scale: individual components are sums with cancellation
+    assert np.allclose(acc.cpu().numpy(), g["acc"], rtol=1e-5, atol=1e-5 * float(np.abs(g["acc"]).max()))
     with tempfile.TemporaryDirectory() as d:
         gm.save_gradient_ratio(loaders, model, nn.CrossEntropyLoss(), SimpleNamespace(save_dir=d, thresholds=None))
         files = sorted(os.listdir(d))

@@ -1,0 +1,14 @@
+#!/bin/bash
+# rocprofv3 kernel-trace of a command on the GPU box; keeps only the small CSV summaries.
+#   tools/prof.sh <tag> <command...>      -> gpurun_out/<tag>_kernel_stats.csv (+ top of the table on stdout)
+set -u
+tag=$1; shift
+out=/tmp/prof_$tag
+rm -rf $out; mkdir -p $out
+export TMPDIR=/tmp
+here=$(pwd)
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $tag -- "$@" ) > $out/run.log 2>&1
+mkdir -p $here/gpurun_out
+f=$(find $out -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then cp $f $here/gpurun_out/${tag}_kernel_stats.csv; head -25 $f | cut -c1-200; else echo "no stats file"; tail -20 $out/run.log; fi
+tail -3 $out/run.log | cut -c1-300

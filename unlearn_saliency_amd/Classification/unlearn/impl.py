@@ -12,7 +12,7 @@ arena and the reference's three per-tensor stages
     _apply_mask_to_grads -> optimizer.step() -> _restore_masked_params   (RL.py:134-140)
 
 (~440 launches + 62 host syncs per step) become ONE
-`salun_masked_sgd_step` launch inside `FusedMaskedSGD.step()`.
+`salun_masked_sgd_step` launch inside `FusedMaskedSGD.step()` (unlearn_saliency_amd/optim.py).
 """
 from __future__ import annotations
 
@@ -22,44 +22,9 @@ from typing import Dict, Optional
 
 import torch
 
-from ... import ops
-from ...dist import all_reduce_mean_, world_size
-from ...flat import FlatArena, arena_of
+from ...flat import arena_of
+from ...optim import FusedMaskedSGD
 from .. import utils
-
-
-class FusedMaskedSGD(torch.optim.Optimizer):
-    """SGD(momentum, weight_decay, dampening 0, no nesterov) over a FlatArena with the saliency
-    mask folded in.  A torch.optim.Optimizer so LR schedulers / state_dict work; `param_groups[0]`
-    carries lr / momentum / weight_decay like torch.optim.SGD's."""
-
-    def __init__(self, arena: FlatArena, lr: float, momentum: float = 0.0, weight_decay: float = 0.0):
-        self.arena = arena
-        super().__init__(arena._params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
-        self.momentum_buffer = arena.new_like() if momentum != 0 else None
-        self.mask_u8: Optional[torch.Tensor] = None
-        self._first_step = True
-        self.steps = 0
-
-    def set_mask(self, mask_u8: Optional[torch.Tensor]) -> None:
-        if mask_u8 is not None:
-            assert mask_u8.dtype == torch.uint8 and mask_u8.numel() == self.arena.n
-        self.mask_u8 = mask_u8
-
-    def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002 - grads stay attached views
-        self.arena.zero_grad()
-
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
-        g = self.param_groups[0]
-        if world_size() > 1:  # data parallel: one all-reduce of the flat gradient (RCCL over xGMI)
-            all_reduce_mean_(self.arena.grads)
-        ops.masked_sgd_step(self.arena.params, self.arena.grads, self.momentum_buffer, self.mask_u8,
-                            g["lr"], g["momentum"], g["weight_decay"], self._first_step)
-        self._first_step = False
-        self.steps += 1
-        return loss
 
 
 def plot_training_curve(training_result, save_dir, prefix):

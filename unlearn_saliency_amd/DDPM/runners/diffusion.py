@@ -1,0 +1,284 @@
+"""`Diffusion` runner: the three hot entry points of the reference's DDPM/runners/diffusion.py —
+
+    generate_mask()     Phase A for the CFG-DDPM U-Net           (reference :933-1039)
+    saliency_unlearn()  masked ε-MSE unlearning loop (rl / ga)   (reference :482-619)
+    save_fim()          diagonal empirical Fisher                 (reference :101-191)
+
+— same constructor (`Diffusion(args, config)`), same `args` / YAML fields, same artefacts
+(`results/cifar10/mask/{label}/with_0.5.pt` with `module.`-prefixed int64 tensors; `ckpts/ckpt.pth` =
+`[model_state, optimizer_state, step]`; `fisher_dict.pkl`).  Sampling / pre-training / FID stay out of
+scope.
+
+What is different underneath (MI355X-first):
+  * one process per GPU + RCCL instead of nn.DataParallel's per-step parameter broadcast / output gather;
+    state_dict keys still carry the `module.` prefix so checkpoints and masks interoperate;
+  * gradients never leave the device: the reference moves all 334 gradients to the CPU every batch
+    (154.5 MB D2H, :995) and the int64 mask back to the GPU every step (309 MB H2D, :592);
+    here Σ grads is a flat fp32 vector updated by `salun_saliency_accumulate` with the per-batch clip
+    coefficient read from device memory, and the mask is a resident flat u8 vector;
+  * clip → mask → Adam is `salun_grad_sqnorm` + `salun_masked_adam_step`; q-sample and ε-MSE are
+    `salun_qsample` / `salun_sqerr_loss`.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import pickle
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from ... import dist as sdist
+from ... import ops
+from ...flat import FlatArena, arena_of
+from ..datasets import data_transform, get_forget_dataset
+from ..functions import cycle, get_optimizer
+from ..functions.losses import loss_registry_conditional, q_sample
+from ..models.diffusion import Conditional_Model
+
+DP_PREFIX = "module."  # reference checkpoints / masks come from nn.DataParallel-wrapped models
+
+
+def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_timesteps):
+    """float64 numpy β_1..β_T (reference :36-66)."""
+    T = num_diffusion_timesteps
+    if beta_schedule == "quad":
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=np.float64) ** 2
+    elif beta_schedule == "linear":
+        betas = np.linspace(beta_start, beta_end, T, dtype=np.float64)
+    elif beta_schedule == "const":
+        betas = beta_end * np.ones(T, dtype=np.float64)
+    elif beta_schedule == "jsd":
+        betas = 1.0 / np.linspace(T, 1, T, dtype=np.float64)
+    elif beta_schedule == "sigmoid":
+        betas = 1 / (np.exp(-np.linspace(-6, 6, T)) + 1) * (beta_end - beta_start) + beta_start
+    else:
+        raise NotImplementedError(beta_schedule)
+    assert betas.shape == (T,)
+    return betas
+
+
+def antithetic_timesteps(n: int, num_timesteps: int, device) -> torch.Tensor:
+    """t ~ randint(T) for n//2+1 draws, mirrored with T-t-1, truncated to n (reference :530-533)."""
+    t = torch.randint(low=0, high=num_timesteps, size=(n // 2 + 1,)).to(device)
+    return torch.cat([t, num_timesteps - t - 1], dim=0)[:n]
+
+
+def strip_prefix(state: dict, prefix: str = DP_PREFIX) -> "OrderedDict[str, torch.Tensor]":
+    return OrderedDict((k[len(prefix):] if k.startswith(prefix) else k, v) for k, v in state.items())
+
+
+def add_prefix(state: dict, prefix: str = DP_PREFIX) -> "OrderedDict[str, torch.Tensor]":
+    return OrderedDict((prefix + k, v) for k, v in state.items())
+
+
+class Diffusion(object):
+    def __init__(self, args, config):
+        self.args, self.config = args, config
+        if not torch.cuda.is_available():
+            raise RuntimeError("the DDPM hot path needs a ROCm device (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.model_var_type = config.model.var_type
+        betas = get_beta_schedule(beta_schedule=config.diffusion.beta_schedule,
+                                  beta_start=config.diffusion.beta_start, beta_end=config.diffusion.beta_end,
+                                  num_diffusion_timesteps=config.diffusion.num_diffusion_timesteps)
+        self.betas = torch.from_numpy(betas).float().to(self.device)
+        self.num_timesteps = self.betas.shape[0]
+        alphas_cumprod = (1.0 - self.betas).cumprod(dim=0)
+        prev = torch.cat([torch.ones(1, device=self.device), alphas_cumprod[:-1]], dim=0)
+        posterior_variance = self.betas * (1.0 - prev) / (1.0 - alphas_cumprod)
+        if self.model_var_type == "fixedlarge":
+            self.logvar = self.betas.log()
+        elif self.model_var_type == "fixedsmall":
+            self.logvar = posterior_variance.clamp(min=1e-20).log()
+
+    # ------------------------------------------------------------------ helpers
+    def _load_model(self):
+        """Conditional_Model on this GPU with `states[0]` of `{ckpt_folder}/ckpts/ckpt.pth` loaded (keys with or
+        without the DataParallel prefix).  `args.init_model` (a state_dict) or a missing checkpoint with
+        `args.synthetic` keeps the random initialisation (benchmarks: no checkpoints offline)."""
+        args = self.args
+        model = Conditional_Model(self.config).to(self.device)
+        path = os.path.join(args.ckpt_folder, "ckpts/ckpt.pth") if getattr(args, "ckpt_folder", None) else None
+        if path and os.path.exists(path):
+            print("Loading checkpoints {}".format(args.ckpt_folder))
+            states = torch.load(path, map_location=self.device, weights_only=False)
+            model.load_state_dict(strip_prefix(states[0]), strict=True)
+        elif not getattr(args, "synthetic", False):
+            raise FileNotFoundError(f"{path}: original-model checkpoint not found (pass --synthetic to benchmark "
+                                    "a randomly initialised U-Net)")
+        return model
+
+    def _loaders(self):
+        return get_forget_dataset(self.args, self.config, self.args.label_to_forget, device=self.device,
+                                  synthetic=True if getattr(self.args, "synthetic", False) else None)
+
+    # --------------------------------------------------------- Phase A: mask
+    def accumulate_saliency(self, model, forget_loader, arena: FlatArena = None) -> torch.Tensor:
+        """Σ_batches clip_1.0(∇ ε-MSE of the CFG-combined prediction), model in eval mode (reference :957-996).
+        Exact under data parallel: each rank back-propagates its shard's share of the global-batch mean, the
+        flat gradient is all-reduced per batch (the clip needs the global norm), then accumulated."""
+        args, config = self.args, self.config
+        arena = arena or arena_of(model)
+        acc = arena.new_like()
+        sq = torch.zeros(1, device=self.device)
+        model.eval()
+        ws = sdist.world_size()
+        for x, forget_c in forget_loader:
+            n = x.size(0)
+            x = data_transform(config, x.to(self.device))
+            e = torch.randn_like(x)
+            t = antithetic_timesteps(n, self.num_timesteps, self.device)
+            xt = q_sample(x, t, e, self.betas)
+            output = model(xt, t.float(), forget_c, cond_scale=args.cond_scale, mode="test")
+            loss = ops.eps_mse(e, output)
+            if ws > 1:  # local mean -> share of the global-batch mean
+                cnt = torch.tensor([float(n)], device=self.device)
+                sdist.all_reduce_sum_(cnt)
+                loss = loss * (n / float(cnt.item()))
+            arena.zero_grad()
+            loss.backward()
+            sdist.all_reduce_sum_(arena.grads)
+            clip = getattr(config.optim, "grad_clip", None)
+            if clip:
+                ops.grad_sqnorm(arena.grads, sq)
+                ops.saliency_accumulate(acc, arena.grads, sqnorm=sq, max_norm=clip)
+            else:
+                ops.saliency_accumulate(acc, arena.grads, 1.0)
+        return acc
+
+    def generate_mask(self):
+        args, config = self.args, self.config
+        logging.info("Generating mask of diffusion to achieve gradient sparsity. "
+                     f"Gamma: {config.training.gamma}, lambda: {config.training.lmbda}")
+        _, forget_loader = self._loaders()
+        model = self._load_model()
+        arena = arena_of(model)
+        t0 = time.time()
+        acc = self.accumulate_saliency(model, forget_loader, arena)
+        threshold_list = [0.5]  # reference :1006
+        masks = ops.mask_topk(acc, [int(arena.n * r) for r in threshold_list])
+        torch.cuda.synchronize()
+        logging.info(f"saliency + top-k: {time.time() - t0:.2f}s")
+        mask_path = os.path.join(getattr(args, "mask_dir", "results/cifar10/mask"), str(args.label_to_forget))
+        if sdist.rank() == 0:
+            os.makedirs(mask_path, exist_ok=True)
+            for r, m in zip(threshold_list, masks):
+                print(r)
+                torch.save(arena.unpack_mask(m, prefix=DP_PREFIX), os.path.join(mask_path, f"with_{str(r)}.pt"))
+        sdist.barrier()
+        return dict(zip(threshold_list, masks))
+
+    # ------------------------------------------------- Phase B: masked unlearning
+    def unlearn_step(self, model, optimizer, remain_batch, forget_batch):
+        """One iteration of the reference loop body (:520-593); returns the loss tensor (no host sync)."""
+        args, config = self.args, self.config
+        b = self.betas
+        remain_x, remain_c = remain_batch
+        n = remain_x.size(0)
+        remain_x = data_transform(config, remain_x.to(self.device))
+        e = torch.randn_like(remain_x)
+        t = antithetic_timesteps(n, self.num_timesteps, self.device)
+        remain_loss = loss_registry_conditional[config.model.type](model, remain_x, t, remain_c, e, b)
+
+        forget_x, forget_c = forget_batch
+        n = forget_x.size(0)
+        forget_x = data_transform(config, forget_x.to(self.device))
+        e = torch.randn_like(forget_x)
+        t = antithetic_timesteps(n, self.num_timesteps, self.device)
+        if args.method == "ga":
+            forget_loss = -loss_registry_conditional[config.model.type](model, forget_x, t, forget_c, e, b)
+        else:
+            xt = q_sample(forget_x, t, e, b)
+            output = model(xt, t.float(), forget_c, mode="train")
+            if args.method == "rl":
+                pseudo_c = torch.full(forget_c.shape, (args.label_to_forget + 1) % 10, device=forget_c.device)
+                with torch.no_grad():
+                    pseudo = model(xt, t.float(), pseudo_c, mode="train")
+                forget_loss = ops.mse_loss(pseudo, output)
+            else:
+                raise ValueError(f"unknown --method {args.method!r} (rl | ga)")
+        loss = forget_loss + args.alpha * remain_loss
+
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.clip_grad_norm_(config.optim.grad_clip)  # clip -> mask -> Adam, fused into step()
+        optimizer.step()
+        return loss
+
+    def saliency_unlearn(self):
+        args, config = self.args, self.config
+        remain_loader, forget_loader = self._loaders()
+        remain_iter, forget_iter = cycle(remain_loader), cycle(forget_loader)
+        mask = torch.load(args.mask_path, map_location=self.device, weights_only=False) if args.mask_path else None
+        model = self._load_model()
+        arena = arena_of(model)
+        optimizer = get_optimizer(config, arena=arena)
+        if mask:
+            optimizer.set_mask(arena.pack_mask(strip_prefix(mask)))
+        if config.model.ema:
+            raise NotImplementedError("EMA is off in cifar10_saliency_unlearn.yml (out of scope, SURVEY.md §2 D6)")
+        model.train()
+        start = time.time()
+        for step in range(0, config.training.n_iters):
+            model.train()
+            loss = self.unlearn_step(model, optimizer, next(remain_iter), next(forget_iter))
+            if (step + 1) % config.training.log_freq == 0:
+                end = time.time()
+                logging.info(f"step: {step}, loss: {loss.item()}, time: {end - start}")
+                start = time.time()
+            if (step + 1) % config.training.snapshot_freq == 0 and sdist.rank() == 0:
+                states = [add_prefix(model.state_dict()), optimizer.state_dict(), step]
+                torch.save(states, os.path.join(config.ckpt_dir, "ckpt.pth"))
+        return model
+
+    # ------------------------------------------------------------------ Fisher
+    def save_fim(self, samples=None):
+        """F = (1/N) Σ_samples (Σ_t ∇ℓ_t(x, c))²  (reference :101-191): per sample, the ε-MSE gradient is summed
+        over all T timesteps in `n_chunks` chunks (one backward per chunk), then squared and accumulated by
+        `salun_fim_square_accumulate`.  Samples shard over ranks; F is all-reduced once at the end.
+        `samples`: optional iterable of (x[1,3,H,W] in [0,1], c[1]) — default: {ckpt_folder}/class_samples."""
+        args, config = self.args, self.config
+        model = self._load_model()
+        model.eval()
+        arena = arena_of(model)
+        if samples is None:
+            samples = _image_folder_samples(os.path.join(args.ckpt_folder, "class_samples"), self.device)
+        samples = list(samples)
+        n_data = len(samples)
+        lo, hi = sdist.shard_bounds(n_data)
+        F = arena.new_like()
+        tmp = arena.new_like()
+        ts = torch.chunk(torch.arange(0, self.num_timesteps), args.n_chunks)
+        for x, c in samples[lo:hi]:
+            x, c = x.to(self.device), c.to(self.device)  # NB: not rescaled to [-1,1], as in the reference (:106-109)
+            for _t in ts:
+                loss = 0
+                for i in range(len(_t)):
+                    e = torch.randn_like(x)
+                    t = torch.tensor([_t[i]]).expand(x.size(0)).to(self.device)
+                    loss = loss + loss_registry_conditional[config.model.type](model, x, t, c, e, self.betas,
+                                                                              keepdim=True)
+                arena.zero_grad()
+                loss.sum().backward()  # one sample per pass => the per-sample gradient
+                ops.saliency_accumulate(tmp, arena.grads, 1.0)
+            ops.fim_square_accumulate(F, tmp, float(n_data))
+        sdist.all_reduce_sum_(F)
+        fisher_dict = arena.view_dict(F, prefix=DP_PREFIX)
+        if sdist.rank() == 0 and getattr(args, "ckpt_folder", None):
+            with open(os.path.join(args.ckpt_folder, "fisher_dict.pkl"), "wb") as f:
+                pickle.dump(OrderedDict((k, v.clone()) for k, v in fisher_dict.items()), f)
+        return fisher_dict
+
+
+def _image_folder_samples(root, device):
+    """Minimal ImageFolder(ToTensor) reader: root/<class>/*.png|jpg -> (x[1,3,H,W], c[1]), needs PIL."""
+    from PIL import Image
+    classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+    for ci, cname in enumerate(classes):
+        for fn in sorted(os.listdir(os.path.join(root, cname))):
+            img = np.asarray(Image.open(os.path.join(root, cname, fn)).convert("RGB"))
+            x = torch.from_numpy(img).permute(2, 0, 1).float().div(255)[None]
+            yield x.to(device), torch.tensor([ci], device=device)

@@ -1,0 +1,95 @@
+"""Fused optimizers over a FlatArena: one HIP launch per step for the whole model.
+
+Both are `torch.optim.Optimizer`s (LR schedulers, `param_groups`, `state_dict` keep working) whose
+`step()` is: [multi-GPU: one all-reduce(mean) of the flat gradient] -> one kernel that applies
+the saliency mask, the update rule and (SGD) the reference's restore of masked-out weights.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .dist import all_reduce_mean_, world_size
+from .flat import FlatArena
+
+
+class _FlatOptimizer(torch.optim.Optimizer):
+    def __init__(self, arena: FlatArena, defaults: dict):
+        self.arena = arena
+        super().__init__(arena._params, defaults)
+        self.mask_u8: Optional[torch.Tensor] = None
+        self.steps = 0
+
+    def set_mask(self, mask_u8: Optional[torch.Tensor]) -> None:
+        """Flat u8 0/1 vector (FlatArena.pack_mask) or None for an unmasked update."""
+        if mask_u8 is not None:
+            assert mask_u8.dtype == torch.uint8 and mask_u8.numel() == self.arena.n
+        self.mask_u8 = mask_u8
+
+    def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002 - grads stay attached views
+        self.arena.zero_grad()
+
+    def _sync_grads(self) -> None:
+        if world_size() > 1:  # data parallel: ONE collective over the flat gradient (RCCL over xGMI)
+            all_reduce_mean_(self.arena.grads)
+
+
+class FusedMaskedSGD(_FlatOptimizer):
+    """torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov=False) semantics
+    (Classification/unlearn/impl.py:68-73) + `_apply_mask_to_grads` + `_restore_masked_params`
+    (Classification/unlearn/RL.py:11-34) in one `salun_masked_sgd_step` launch."""
+
+    def __init__(self, arena: FlatArena, lr: float, momentum: float = 0.0, weight_decay: float = 0.0):
+        super().__init__(arena, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.momentum_buffer = arena.new_like() if momentum != 0 else None
+        self._first_step = True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self._sync_grads()
+        ops.masked_sgd_step(self.arena.params, self.arena.grads, self.momentum_buffer, self.mask_u8,
+                            g["lr"], g["momentum"], g["weight_decay"], self._first_step)
+        self._first_step = False
+        self.steps += 1
+        return loss
+
+
+class FusedMaskedAdam(_FlatOptimizer):
+    """clip_grad_norm_(max_norm) -> mask multiply -> torch.optim.Adam(amsgrad=False) step
+    (DDPM/runners/diffusion.py:582-593, DDPM/functions/__init__.py:9-18) as two launches:
+    `salun_grad_sqnorm` (deterministic reduction, result stays on the device) and
+    `salun_masked_adam_step` (reads the norm from device memory: no host sync anywhere)."""
+
+    def __init__(self, arena: FlatArena, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, amsgrad: bool = False, grad_clip: Optional[float] = None):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is off in every reference config (cifar10_saliency_unlearn.yml:54)")
+        super().__init__(arena, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.exp_avg = arena.new_like()
+        self.exp_avg_sq = arena.new_like()
+        self.grad_clip = grad_clip
+        self._sqnorm = torch.zeros(1, dtype=torch.float32, device=arena.device)
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """Arms clipping for the next step() and returns the squared norm (device tensor, no sync).
+        Mirrors the call order of the reference loop: clip, then mask, then step."""
+        self.grad_clip = max_norm
+        return self._sqnorm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self._sync_grads()
+        self.steps += 1
+        sq = None
+        if self.grad_clip is not None:
+            sq = ops.grad_sqnorm(self.arena.grads, self._sqnorm)
+        ops.masked_adam_step(self.arena.params, self.arena.grads, self.exp_avg, self.exp_avg_sq, self.mask_u8,
+                             g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.steps,
+                             sqnorm=sq, max_norm=self.grad_clip if self.grad_clip is not None else 1.0)
+        return loss

@@ -155,7 +155,9 @@ def main():
     from unlearn_saliency_amd.flat import arena_of
     from unlearn_saliency_amd import ops
 
-    model, forget_loader, retain_loader = build_workload(device, rank, world, a.batch_size)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # stdout carries exactly one JSON line
+        model, forget_loader, retain_loader = build_workload(device, rank, world, a.batch_size)
     torch.backends.cudnn.deterministic = bool(a.deterministic)  # setup_seed() above turned it on
     torch.backends.cudnn.benchmark = True
     if a.channels_last:
@@ -168,7 +170,8 @@ def main():
     if a.no_mask_gen:
         mask_u8 = ops.mask_topk(ops.fill_normal(N18, 5, 0.0, 1e-3), [int(N18 * 0.5)])[0]
     else:
-        mask_u8, mask_gen = time_mask_gen(model, forget_loader, criterion)
+        with contextlib.redirect_stdout(sys.stderr):
+            mask_u8, mask_gen = time_mask_gen(model, forget_loader, criterion)
     assert ops.mask_popcount(mask_u8) == int(N18 * 0.5)
 
     opt = FusedMaskedSGD(arena, 0.013, momentum=0.9, weight_decay=5e-4)
@@ -238,7 +241,8 @@ def main():
                         "note": "convolutions/GEMMs run in MIOpen/rocBLAS fp32 through PyTorch-ROCm"},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.batch_size, a.cpu_steps)
+            with contextlib.redirect_stdout(sys.stderr):
+                out["cpu_baseline"] = cpu_baseline(a.batch_size, a.cpu_steps)
         print(json.dumps(out), flush=True)
     sdist.barrier()
     if sdist.is_dist():

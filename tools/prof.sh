@@ -7,7 +7,9 @@ out=/tmp/prof_$tag
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
 here=$(pwd)
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $tag -- "$@" ) > $out/run.log 2>&1
+args=()
+for a in "$@"; do if [ -f "$here/$a" ]; then args+=("$here/$a"); else args+=("$a"); fi; done
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -o $tag -- "${args[@]}" ) > $out/run.log 2>&1
 mkdir -p $here/gpurun_out
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 if [ -n "$f" ]; then cp $f $here/gpurun_out/${tag}_kernel_stats.csv; head -25 $f | cut -c1-200; else echo "no stats file"; tail -20 $out/run.log; fi

@@ -25,6 +25,7 @@ constexpr int D1_BINS = 1024;  // (key >> 10) & 1023
 constexpr int D2_BINS = 1024;  // key & 1023
 constexpr int CHUNK_VEC = 4 * SALUN_BLOCK;  // float4 per chunk (4 sub-vectors per lane)
 constexpr int CHUNK = CHUNK_VEC * 4;        // 4096 elements: the tie-ordering granule
+constexpr int HIST_MAX_GRID = 512;
 
 enum Mode : uint32_t { MODE_NONE = 0, MODE_ALL = 1, MODE_GE = 2, MODE_ORDERED = 3 };
 
@@ -539,21 +540,25 @@ SALUN_EXPORT int salun_mask_topk(const float *acc, int64_t n, const int64_t *ks,
   const bool aligned = salun_aligned16(acc);
   if (hipMemsetAsync(state, 0, sizeof(TopkState), st) != hipSuccess) return SALUN_EIO;
   const int grid = salun_grid_for(n, CHUNK);
+  // Histogram kernels end with one global atomic per non-empty bin per workgroup, all workgroups hitting the
+  // same few hundred addresses: keep that chain short (2 workgroups per CU) — the read side still has
+  // 8 waves x 4 KiB in flight per CU.
+  const int hgrid = grid < HIST_MAX_GRID ? grid : HIST_MAX_GRID;
   // dynamic LDS of the pass-1/2 histogram kernels: 2 KiB lut + one 4 KiB histogram per threshold
   const size_t lds_bytes = D0_BINS + sizeof(uint32_t) * (size_t)nk * 1024;
 
-  if (aligned) hipLaunchKernelGGL(k_hist0<true>, dim3(grid), dim3(SALUN_BLOCK), 0, st, acc, n, state);
-  else hipLaunchKernelGGL(k_hist0<false>, dim3(grid), dim3(SALUN_BLOCK), 0, st, acc, n, state);
+  if (aligned) hipLaunchKernelGGL(k_hist0<true>, dim3(hgrid), dim3(SALUN_BLOCK), 0, st, acc, n, state);
+  else hipLaunchKernelGGL(k_hist0<false>, dim3(hgrid), dim3(SALUN_BLOCK), 0, st, acc, n, state);
   SALUN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_select<0>, dim3(1), dim3(1024), 0, st, state, n, kl);
   SALUN_LAUNCH_CHECK();
-  if (aligned) hipLaunchKernelGGL((k_hist12<1, true>), dim3(grid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
-  else hipLaunchKernelGGL((k_hist12<1, false>), dim3(grid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
+  if (aligned) hipLaunchKernelGGL((k_hist12<1, true>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
+  else hipLaunchKernelGGL((k_hist12<1, false>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
   SALUN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_select<1>, dim3(1), dim3(1024), 0, st, state, n, kl);
   SALUN_LAUNCH_CHECK();
-  if (aligned) hipLaunchKernelGGL((k_hist12<2, true>), dim3(grid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
-  else hipLaunchKernelGGL((k_hist12<2, false>), dim3(grid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
+  if (aligned) hipLaunchKernelGGL((k_hist12<2, true>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
+  else hipLaunchKernelGGL((k_hist12<2, false>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
   SALUN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_select<2>, dim3(1), dim3(1024), 0, st, state, n, kl);
   SALUN_LAUNCH_CHECK();

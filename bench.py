@@ -56,6 +56,9 @@ def parse():
                     help="1 = keep cudnn.deterministic=True as the reference's setup_seed sets it (restricts MIOpen's "
                          "algorithm choice); 0 = let MIOpen pick its fastest fp32 kernels (same math, fp32)")
     ap.add_argument("--channels_last", type=int, default=0, help="1 = NHWC activations/weights")
+    ap.add_argument("--salun_conv", type=int, default=1,
+                    help="1 = convolutions on the hand-written fp32 MFMA kernels (csrc/salun_conv.hip); "
+                         "0 = library (MIOpen) convolutions")
     return ap.parse_args()
 
 
@@ -162,6 +165,10 @@ def main():
     torch.backends.cudnn.benchmark = True
     if a.channels_last:
         model = model.to(memory_format=torch.channels_last)
+    n_salun_convs = 0
+    if a.salun_conv and not a.channels_last:
+        from unlearn_saliency_amd.conv import use_salun_convs
+        n_salun_convs = use_salun_convs(model)
     criterion = nn.CrossEntropyLoss()
     arena = arena_of(model)
     assert arena.n == N18
@@ -225,7 +232,7 @@ def main():
                                    "SGD lr 0.013 momentum 0.9 wd 5e-4, RandomCrop+flip on device",
                        "per_gpu_batch": a.batch_size, "global_batch": a.batch_size * world,
                        "parallelism": f"dp{world}", "params": N18, "cudnn_deterministic": bool(a.deterministic),
-                       "channels_last": bool(a.channels_last)},
+                       "channels_last": bool(a.channels_last), "salun_mfma_convs": n_salun_convs},
             "samples_per_sec": steps_per_s * a.batch_size,
             "mask_gen_sec": None if mask_gen is None else mask_gen["total_sec"],
             "mask_gen": mask_gen,
@@ -238,7 +245,9 @@ def main():
             "fwd_bwd": {"bound": "mfma", "gflop_per_step": FWD_BWD_GFLOP_PER_IMG * a.batch_size,
                         "achieved_tflops_whole_step": FWD_BWD_GFLOP_PER_IMG * a.batch_size / (1e3 * dt / a.steps) ,
                         "peak_tflops_fp32": FP32_MATRIX_PEAK_TF,
-                        "note": "convolutions/GEMMs run in MIOpen/rocBLAS fp32 through PyTorch-ROCm"},
+                        "note": ("convolutions: hand-written fp32 MFMA implicit-GEMM kernels (salun_conv2d_*); "
+                                 "BN/ReLU/pool/fc: PyTorch-ROCm") if n_salun_convs else
+                                "convolutions/GEMMs run in MIOpen/rocBLAS fp32 through PyTorch-ROCm"},
         }
         if world == 1 and not a.no_cpu_baseline:
             with contextlib.redirect_stdout(sys.stderr):

@@ -186,6 +186,31 @@ int salun_sqerr_loss(const float *a /*dev*/, const float *b /*dev*/, int64_t B,
 int salun_fim_square_accumulate(float *F /*dev*/, float *tmp /*dev*/, double n_data,
                                 int64_t n, salun_stream_t stream);
 
+/* ------------------------------------------------------------------ K8 --
+ * fp32 2-D convolution on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains), NCHW
+ * activations, OIHW weights read in place from the flat arena.  Replaces the library convolution calls
+ * autograd issues for `nn.Conv2d` forward / backward in the models on the path
+ *   (Classification/models/ResNet.py:58-74,218-220; DDPM/models/diffusion.py:54-56,71-73,103-122,154-165,
+ *    245-247,325-327) — see DESIGN.md §3 for why (the library picks naive kernels for these fp32 shapes).
+ * Supported: square filter R in {1,3}, stride in {1,2}, dilation 1, groups 1; `pad` is the low-side
+ * (top/left) padding, the high side is implied by P,Q; Q (forward / weight) resp. W (backward-data) must be
+ * a power of two <= 128 and the pixel space must tile (see csrc/salun_conv.hip make_geom).  Unsupported
+ * shapes return SALUN_EINVAL and the caller uses the library convolution.
+ *   forward        y[N,K,P,Q]  = conv(x[N,C,H,W], w[K,C,R,R]) (+ bias[K] if non-NULL)
+ *   backward_data  dx[N,C,H,W] = conv_transpose(dy[N,K,P,Q], w)
+ *   backward_weight dw[K,C,R,R] (= or += if accumulate) sum over n,p,q of dy * x; deterministic
+ *                  (pixel range split over workgroups -> partials in `ws` -> fixed-order reduce). */
+int salun_conv2d_forward(const float *x /*dev*/, const float *w /*dev*/, const float *bias /*dev or NULL*/,
+                         float *y /*dev*/, int N, int C, int H, int W, int K, int R, int stride, int pad,
+                         int P, int Q, salun_stream_t stream);
+int salun_conv2d_backward_data(const float *dy /*dev*/, const float *w /*dev*/, float *dx /*dev*/, int N, int C,
+                               int H, int W, int K, int R, int stride, int pad, int P, int Q,
+                               salun_stream_t stream);
+size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int R, int P, int Q);
+int salun_conv2d_backward_weight(const float *x /*dev*/, const float *dy /*dev*/, float *dw /*dev*/, int N, int C,
+                                 int H, int W, int K, int R, int stride, int pad, int P, int Q, int accumulate,
+                                 void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+
 /* ------------------------------------------------------------------ K0 --
  * Device-resident CIFAR batch assembly (replaces the host DataLoader path
  * Classification/dataset.py:542-556 + main_random.py:38-48: PIL RandomCrop(32,4)

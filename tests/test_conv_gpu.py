@@ -1,0 +1,100 @@
+"""MFMA convolution kernels (forward / backward-data / backward-weight) vs PyTorch's fp32 convolution
+on the CPU, for every layer shape of ResNet-18 (CIFAR) and the DDPM U-Net families, plus the module swap.
+fp32 FMA chains in a different summation order: tolerance 1e-5 of the tensor's scale (north_star: 1e-5 rel)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (N, C, H, K, R, stride, pad)
+SHAPES = [
+    (8, 3, 32, 64, 3, 1, 1),      # ResNet stem (C = 3: ragged reduction chunk)
+    (8, 64, 32, 64, 3, 1, 1),     # layer1
+    (8, 64, 32, 128, 3, 2, 1),    # layer2.0.conv1
+    (8, 64, 32, 128, 1, 2, 0),    # layer2.0.downsample
+    (8, 128, 16, 128, 3, 1, 1),
+    (16, 128, 16, 256, 3, 2, 1),
+    (16, 128, 16, 256, 1, 2, 0),
+    (16, 256, 8, 256, 3, 1, 1),
+    (32, 256, 8, 512, 3, 2, 1),
+    (32, 256, 8, 512, 1, 2, 0),
+    (32, 512, 4, 512, 3, 1, 1),
+    (3, 64, 8, 64, 3, 1, 1),      # ragged: N not a multiple of the images-per-tile
+    (4, 256, 16, 128, 1, 1, 0),   # DDPM nin_shortcut / attention projections
+    (4, 384, 16, 256, 3, 1, 1),   # DDPM up-block with concatenated skip
+    (4, 128, 32, 3, 3, 1, 1),     # DDPM conv_out (K = 3: masked channel tile)
+    (2, 40, 16, 72, 3, 1, 1),     # channel counts that are not multiples of 32
+]
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("N,C,H,K,R,stride,pad", SHAPES)
+def test_conv_kernels_match_torch_cpu(N, C, H, K, R, stride, pad):
+    from unlearn_saliency_amd import ops
+    x = _rand((N, C, H, H), 1)
+    w = _rand((K, C, R, R), 2, 0.1)
+    b = _rand((K,), 3)
+    P = (H + 2 * pad - R) // stride + 1
+    y_ref = F.conv2d(x, w, b, stride, pad)
+    dy = _rand(tuple(y_ref.shape), 4)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
+    xd, wd, bd, dyd = x.cuda(), w.cuda(), b.cuda(), dy.cuda()
+    y = ops.conv2d_forward(xd, wd, bd, stride, pad, P, P)
+    assert y is not None, "shape unexpectedly outside the tiling domain"
+    tol = lambda ref: 2e-5 * float(ref.abs().max())
+    assert torch.allclose(y.cpu(), y_ref, rtol=1e-5, atol=tol(y_ref))
+    dx = ops.conv2d_backward_data(dyd, wd, x.shape, stride, pad)
+    assert dx is not None and torch.allclose(dx.cpu(), dx_ref, rtol=1e-5, atol=tol(dx_ref))
+    dw = ops.conv2d_backward_weight(xd, dyd, w.shape, stride, pad)
+    assert dw is not None and torch.allclose(dw.cpu(), dw_ref, rtol=1e-5, atol=tol(dw_ref))
+    # deterministic run to run
+    assert torch.equal(dw, ops.conv2d_backward_weight(xd, dyd, w.shape, stride, pad))
+    assert torch.equal(y, ops.conv2d_forward(xd, wd, bd, stride, pad, P, P))
+
+
+def test_asymmetric_padding_downsample():
+    """DDPM Downsample: pad (0,1,0,1) then 3x3 stride 2 (DDPM/models/diffusion.py:75-79)."""
+    from unlearn_saliency_amd.conv import conv2d_lowpad
+    x = _rand((4, 128, 32, 32), 5).cuda().requires_grad_(True)
+    w = _rand((128, 128, 3, 3), 6, 0.05).cuda().requires_grad_(True)
+    b = _rand((128,), 7).cuda().requires_grad_(True)
+    y = conv2d_lowpad(x, w, b, 2, 0, 16, 16)
+    y.square().sum().backward()
+    x2, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    y2 = F.conv2d(F.pad(x2, (0, 1, 0, 1)), w2, b2, stride=2, padding=0)
+    y2.square().sum().backward()
+    for a, r in ((y, y2), (x.grad, x2.grad), (w.grad, w2.grad), (b.grad, b2.grad)):
+        assert torch.allclose(a, r, rtol=1e-4, atol=3e-5 * float(r.abs().max()))
+
+
+def test_unsupported_shape_falls_back():
+    from unlearn_saliency_amd import ops
+    x = torch.randn(2, 8, 12, 12, device="cuda")  # width 12 is not a power of two
+    w = torch.randn(8, 8, 3, 3, device="cuda")
+    assert ops.conv2d_forward(x, w, None, 1, 1, 12, 12) is None
+
+
+def test_module_swap_resnet18_forward_backward():
+    from unlearn_saliency_amd.Classification.models import model_dict
+    from unlearn_saliency_amd.conv import SalunConv2d, use_salun_convs
+    torch.manual_seed(0)
+    ref = model_dict["resnet18"](num_classes=10).cuda()
+    mine = model_dict["resnet18"](num_classes=10).cuda()
+    mine.load_state_dict(ref.state_dict())
+    n = use_salun_convs(mine)
+    assert n == 20 and isinstance(mine.conv1, SalunConv2d)
+    assert list(mine.state_dict().keys()) == list(ref.state_dict().keys())
+    x = torch.rand(32, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (32,), device="cuda")
+    for m in (ref, mine):
+        m.train()
+        F.cross_entropy(m(x), y).backward()
+    for (k, p), q in zip(ref.named_parameters(), mine.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-3, atol=2e-4 * float(p.grad.abs().max())), k

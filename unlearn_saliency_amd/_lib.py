@@ -48,6 +48,11 @@ SIGNATURES = {
     "salun_sqerr_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
     "salun_fim_square_accumulate": (c_int, [c_void_p, c_void_p, c_double, c_int64, c_void_p]),
+    "salun_conv2d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "salun_conv2d_backward_data": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "salun_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int] * 6),
+    "salun_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_size_t,
+                                                                                          c_void_p]),
     "salun_image_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                   c_int, c_void_p]),
     "salun_fill_uniform": (c_int, [c_void_p, c_int64, c_uint64, c_double, c_double, c_void_p]),

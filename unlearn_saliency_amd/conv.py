@@ -1,0 +1,83 @@
+"""`nn.Conv2d` on the hand-written MFMA convolution kernels (csrc/salun_conv.hip).
+
+`use_salun_convs(model)` re-classes every eligible `nn.Conv2d` of a model to `SalunConv2d` in place —
+parameters, names and state_dict are untouched (the weights stay views of the flat arena) — so forward,
+backward-data and backward-weight run as `salun_conv2d_*` launches instead of whatever the library's
+heuristics pick for fp32 on gfx950 (`naive_conv_*` at > 1 s per ResNet-18 step on a cold
+find-db).  Shapes outside the kernels' tiling domain fall back to `F.conv2d` per call.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _eligible(mod: nn.Conv2d) -> bool:
+    k, s, p, d = mod.kernel_size, mod.stride, mod.padding, mod.dilation
+    return (isinstance(p, tuple) and k[0] == k[1] and k[0] in (1, 3) and s[0] == s[1] and s[0] in (1, 2)
+            and p[0] == p[1] and p[0] <= k[0] - 1 and d == (1, 1) and mod.groups == 1
+            and mod.padding_mode == "zeros" and mod.weight.dtype == torch.float32)
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, P, Q):
+        y = ops.conv2d_forward(x, w, bias, stride, pad, P, Q)
+        if y is None:  # outside the tiling domain
+            y = F.conv2d(x, w, bias, stride, pad)
+            ctx.native = False
+        else:
+            ctx.native = True
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.pad, ctx.has_bias = stride, pad, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        stride, pad = ctx.stride, ctx.pad
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_backward_data(dy, w, x.shape, stride, pad) if ctx.native else None
+            if dx is None:
+                dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad) if ctx.native else None
+            if dw is None:
+                dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 2, 3))
+        return dx, dw, db, None, None, None, None
+
+
+class SalunConv2d(nn.Conv2d):
+    """Same parameters / state_dict as nn.Conv2d; fp32 NCHW device tensors go through the MFMA kernels."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+                and not torch.is_autocast_enabled()):
+            R, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+            P = (x.shape[2] + 2 * p - R) // s + 1
+            Q = (x.shape[3] + 2 * p - R) // s + 1
+            return _ConvFn.apply(x, self.weight, self.bias, s, p, P, Q)
+        return super().forward(x)
+
+
+def conv2d_lowpad(x, weight, bias, stride, pad_lo, P, Q):
+    """Functional form with explicit low-side padding and output size (asymmetric padding such as the DDPM
+    downsampler's (0,1,0,1): pad_lo = 0 with P, Q computed for the padded extent)."""
+    return _ConvFn.apply(x, weight, bias, stride, pad_lo, P, Q)
+
+
+def use_salun_convs(model: nn.Module) -> int:
+    """Re-class eligible nn.Conv2d modules in place.  Returns how many were switched."""
+    n = 0
+    for mod in model.modules():
+        if type(mod) is nn.Conv2d and _eligible(mod):
+            mod.__class__ = SalunConv2d
+            n += 1
+    return n

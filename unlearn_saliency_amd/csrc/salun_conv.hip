@@ -1,0 +1,473 @@
+// salun_conv.hip — K8: fp32 2-D convolution forward / backward-data / backward-weight as implicit GEMM on
+// the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains at the 157 TF/s fp32 rate).
+//
+// Why this exists: profiling the ResNet-18 unlearning step (profiles/r01_bench_miopen_naive_kernel_stats.csv)
+// showed the library path choosing `naive_conv_*` / im2col+GEMM kernels for the fp32 NCHW problems of this
+// workload on gfx950 (21 ms per weight-gradient launch, > 1 s per step).  The forward/backward of the models
+// is MFMA-bound by construction, so the convolutions get their own kernels.
+//
+// Layouts are the reference's: activations NCHW, weights OIHW read straight from the flat parameter arena.
+//
+// Forward / backward-data (one kernel, `conv_igemm`): D[k][pix] = sum_{c,r,s} Wt[k][c,r,s] * X[c][pix + (r,s)]
+//   * workgroup = 256 threads = 4 waves; tile = PIXT (64|128) output pixels x KB (32..128) output channels;
+//     A operand = weights (rows = output channels), B operand = input pixels, so a wave's 32 result columns are 32
+//     consecutive pixels and the NCHW store is coalesced;
+//   * per chunk of CC=8 reduction channels the input *patch* (tile rows + halo, zero padded) and the weight slab
+//     are staged in LDS once; the R*S taps are addressed inside the patch (no im2col copy), one ds_read_b32 per
+//     operand per MFMA, bank-conflict-free (odd row strides);
+//   * backward-data is the same loop over the (zero-upsampled for stride 2) output gradient with the weight
+//     slab transposed and tap-flipped while it is staged.
+// Backward-weight (`conv_wgrad`): dW[k][c][r,s] = sum_pix dY[k][pix] * X[c][pix + (r,s)]: reduction over pixels,
+//   9 accumulators (one per tap) per wave, pixel range split over workgroups -> partials -> fixed-order reduce
+//   (deterministic, no float atomics).
+#include "salun_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CC = 8;  // reduction channels staged per chunk
+
+struct ConvGeom {
+  // logical convolution: out[n][k][p][q] = sum x[n][c][p*S - pad + r][q*S - pad + s] * w[k][c][r][s]
+  int N, C, H, W, K, P, Q, pad;
+  // tile decomposition of the output pixel space (n, p, q), q fastest
+  int NI;    // images per tile
+  int TP;    // output rows per image per tile
+  int IH_t;  // patch rows per image, IW_t patch cols
+  int IW_t;
+  int PSZ;   // patch floats per channel (NI*IH_t*IW_t), ch_stride = PSZ | 1
+  int logQ, logTPQ;
+};
+
+// One staged patch position of a thread: where it comes from in a channel plane and where it goes in LDS.
+struct PatchPos {
+  int goff;   // offset inside one (n, c) plane group: n*Cin*HW + ih*W + iw   (channel term added per chunk)
+  int loff;   // offset inside one channel's patch
+  int valid;  // in bounds (else zero fill)
+};
+
+// ---------------------------------------------------------------------------------------------------
+// forward / backward-data
+//   R        filter size (1 or 3), square
+//   STRIDE   forward: convolution stride; DGRAD: upsampling factor of dY (conv stride is 1)
+//   KT       32-channel output tiles per wave
+//   WP x WK  wave grid inside the workgroup: WP pixel tiles x WK channel groups (WP*WK == 4)
+//   DGRAD    backward-data mode
+// `x` is the tensor the patch is read from (forward: input; DGRAD: dY), `y` the tensor written.
+// `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
+// STRIDE and the padding is R-1-pad.
+template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
+                                                  const float *__restrict__ bias, float *__restrict__ y, int N,
+                                                  int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
+                                                  int TP, int IH_t, int IW_t, int logQ, int wC /*w dim1 (C of OIHW)*/,
+                                                  int wK /*w dim0*/) {
+  constexpr int RS = R * R;
+  constexpr int PIXT = WP * 32;        // pixels per workgroup tile
+  constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
+  constexpr int WROW = CC * RS + 1;    // LDS weight row (odd => conflict-free across 32 rows)
+  constexpr int CONV_S = DGRAD ? 1 : STRIDE;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int PSZ = NI * IH_t * IW_t;
+  const int ch_stride = PSZ | 1;
+  float *patch = lds;                   // [CC][ch_stride]
+  float *wl = lds + CC * ch_stride;     // [KB][WROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wp = wave % WP, wk = wave / WP;
+  const int Q = yW, P = yH;
+  const int tiles_per_img = (P * Q) / (TP * Q);  // row bands per image (1 when NI >= 1 image)
+  const int tile = blockIdx.x;
+  const int k0 = blockIdx.y * KB;
+  // tile -> first image / first output row
+  int n0, p0;
+  if (NI > 1) { n0 = tile * NI; p0 = 0; }
+  else { n0 = tile / tiles_per_img; p0 = (tile - n0 * tiles_per_img) * TP; }
+
+  // ---- this lane's output pixel inside the tile (fixed for the whole kernel)
+  const int mloc = wp * 32 + lo;               // 0..PIXT-1
+  const int q_l = mloc & (Q - 1);
+  const int pr = mloc >> logQ;                 // row index inside the tile (over NI*TP rows)
+  const int ni_l = pr / TP, p_l = pr - ni_l * TP;
+  const int pix_off = (ni_l * IH_t + p_l * CONV_S) * IW_t + q_l * CONV_S;  // tap (0,0) position in the patch
+
+  // ---- the (<= 3) patch positions this thread stages for every channel of a chunk
+  constexpr int MAXPOS = 3;
+  PatchPos pos[MAXPOS];
+  const int planeHW = xH * xW;
+  // virtual (possibly upsampled) input extent
+  const int vH = DGRAD ? (xH - 1) * STRIDE + 1 : xH;
+  const int vW = DGRAD ? (xW - 1) * STRIDE + 1 : xW;
+  const int vpad = DGRAD ? (R - 1 - pad) : pad;
+#pragma unroll
+  for (int j = 0; j < MAXPOS; ++j) {
+    const int e = tid + j * 256;
+    pos[j].loff = e;
+    pos[j].valid = 0;
+    pos[j].goff = 0;
+    if (e < PSZ) {
+      const int ni = e / (IH_t * IW_t);
+      const int rem = e - ni * (IH_t * IW_t);
+      const int ih = rem / IW_t, iw = rem - ih * IW_t;
+      const int n = n0 + ni;
+      const int vh = p0 * CONV_S - vpad + ih, vw = -vpad + iw;
+      bool ok = (n < N) && vh >= 0 && vh < vH && vw >= 0 && vw < vW;
+      int sh = vh, sw = vw;
+      if (DGRAD && STRIDE > 1) {
+        ok = ok && (vh % STRIDE == 0) && (vw % STRIDE == 0);
+        sh = vh / STRIDE;
+        sw = vw / STRIDE;
+      }
+      pos[j].valid = ok;
+      pos[j].goff = ok ? (n * xC * planeHW + sh * xW + sw) : 0;
+    }
+  }
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  const int Cred = xC;  // reduction channels = channels of the tensor the patch is read from
+  for (int c0 = 0; c0 < Cred; c0 += CC) {
+    __syncthreads();  // previous chunk fully consumed
+    // ---- stage the input patch: CC channels x PSZ positions
+#pragma unroll
+    for (int j = 0; j < MAXPOS; ++j) {
+      if (pos[j].loff < PSZ) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+          float v = 0.f;
+          if (pos[j].valid && (c0 + c) < Cred) v = x[pos[j].goff + (c0 + c) * planeHW];
+          patch[c * ch_stride + pos[j].loff] = v;
+        }
+      }
+    }
+    // ---- stage the weight slab wl[kk][c*RS + rs] for kk < KB, c < CC
+    if (!DGRAD) {
+      // forward: rows = output channel k, global w[k][c0..c0+CC][rs] is one contiguous run per k
+      for (int e = tid; e < KB * CC * RS; e += 256) {
+        const int kk = e / (CC * RS), j = e - kk * (CC * RS);
+        const int c = j / RS;
+        float v = 0.f;
+        if ((k0 + kk) < wK && (c0 + c) < wC) v = w[(size_t)(k0 + kk) * wC * RS + (size_t)c0 * RS + j];
+        wl[kk * WROW + j] = v;
+      }
+    } else {
+      // backward-data: rows = input channel c of the forward conv (output of this pass), reduction over forward k;
+      // global w[k][c][rs] is contiguous over (c, rs) for a fixed k; taps are flipped while staging
+      for (int e = tid; e < CC * KB * RS; e += 256) {
+        const int kk = e / (KB * RS), rem = e - kk * (KB * RS);  // kk: reduction index (forward k) inside the chunk
+        const int cl = rem / RS, rs = rem - cl * RS;             // cl: output row (forward c) inside the tile
+        float v = 0.f;
+        if ((c0 + kk) < wK && (k0 + cl) < wC) v = w[(size_t)(c0 + kk) * wC * RS + (size_t)(k0 + cl) * RS + rs];
+        wl[cl * WROW + kk * RS + (RS - 1 - rs)] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1)
+#pragma unroll
+    for (int cc = 0; cc < CC; cc += 2) {
+      const float *pbase = patch + (cc + hi) * ch_stride + pix_off;
+      const float *wbase = wl + (wk * KT * 32 + lo) * WROW + (cc + hi) * RS;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+          const float b = pbase[r * IW_t + s];
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            const float a = wbase[t * 32 * WROW + r * R + s];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- epilogue: D[row = channel][col = pixel]; row = (v&3) + 8*(v>>2) + 4*hi
+  const int n_out = n0 + ni_l, p_out = p0 + p_l;
+  if (n_out < N) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int kbase = k0 + (wk * KT + t) * 32;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
+        if (k < yC) {
+          float o = acc[t][v];
+          if (bias) o += bias[k];
+          y[(((size_t)n_out * yC + k) * P + p_out) * Q + q_l] = o;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward-weight.  Workgroup: 4 waves = 2 k-tiles x 2 c-tiles of 32; each wave keeps RS accumulators.
+// grid = (K/64 rounded up, C/64 rounded up, nsplit); split s handles pixel chunks s, s+nsplit, ...
+template <int R, int STRIDE>
+__global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, const float *__restrict__ dy,
+                                                  float *__restrict__ part, int N, int C, int H, int W, int K, int P,
+                                                  int Q, int pad, int NI, int TP, int IH_t, int IW_t, int logQ,
+                                                  int nchunks) {
+  constexpr int RS = R * R;
+  constexpr int PIXC = 64;  // pixels per chunk
+  constexpr int DROW = PIXC + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int PSZ = NI * IH_t * IW_t;
+  const int ch_stride = PSZ | 1;
+  float *xp = lds;                    // [64 c][ch_stride]
+  float *dl = lds + 64 * ch_stride;   // [64 k][DROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int kt = wave & 1, ct = wave >> 1;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int split = blockIdx.z, nsplit = gridDim.z;
+  const int tiles_per_img = (NI > 1) ? 1 : P / TP;
+  const int planeHW = H * W, PQ = P * Q;
+
+  f32x16 acc[RS];
+#pragma unroll
+  for (int t = 0; t < RS; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  for (int chunk = split; chunk < nchunks; chunk += nsplit) {
+    int n0, p0;
+    if (NI > 1) { n0 = chunk * NI; p0 = 0; }
+    else { n0 = chunk / tiles_per_img; p0 = (chunk - n0 * tiles_per_img) * TP; }
+    __syncthreads();
+    // ---- stage x patch: 64 channels x PSZ positions (zero padded)
+    for (int e = tid; e < PSZ; e += 256) {
+      const int ni = e / (IH_t * IW_t);
+      const int rem = e - ni * (IH_t * IW_t);
+      const int ih = rem / IW_t, iw = rem - ih * IW_t;
+      const int n = n0 + ni;
+      const int h = p0 * STRIDE - pad + ih, ww = -pad + iw;
+      const bool ok = (n < N) && h >= 0 && h < H && ww >= 0 && ww < W;
+      const size_t g = ok ? ((size_t)n * C * planeHW + (size_t)h * W + ww) : 0;
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) {
+        float v = 0.f;
+        if (ok && (c0 + c) < C) v = x[g + (size_t)(c0 + c) * planeHW];
+        xp[c * ch_stride + e] = v;
+      }
+    }
+    // ---- stage dy tile: 64 k x 64 pixels
+    for (int e = tid; e < 64 * PIXC; e += 256) {
+      const int kk = e >> 6, m = e & 63;
+      const int q = m & (Q - 1), pr = m >> logQ;
+      const int ni = pr / TP, pl = pr - ni * TP;
+      const int n = n0 + ni;
+      float v = 0.f;
+      if (n < N && (k0 + kk) < K) v = dy[((size_t)n * K + (k0 + kk)) * PQ + (size_t)(p0 + pl) * Q + q];
+      dl[kk * DROW + m] = v;
+    }
+    __syncthreads();
+    const float *arow = dl + (kt * 32 + lo) * DROW;
+    const float *brow = xp + (ct * 32 + lo) * ch_stride;
+#pragma unroll 4
+    for (int j = 0; j < PIXC; j += 2) {
+      const int m = j + hi;
+      const int q = m & (Q - 1), pr = m >> logQ;
+      const int ni = pr / TP, pl = pr - ni * TP;
+      const float a = arow[m];
+      const float *bp = brow + (ni * IH_t + pl * STRIDE) * IW_t + q * STRIDE;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int s = 0; s < R; ++s)
+          acc[r * R + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[r * IW_t + s], acc[r * R + s], 0, 0, 0);
+    }
+  }
+  // ---- partial[split][k][c][rs]
+  float *out = part + (size_t)split * K * C * RS;
+  const int c = c0 + ct * 32 + lo;
+  if (c < C) {
+#pragma unroll
+    for (int t = 0; t < RS; ++t)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = k0 + kt * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+        if (k < K) out[((size_t)k * C + c) * RS + t] = acc[t][v];
+      }
+  }
+}
+
+// dw[i] (+)= sum_s part[s][i], fixed order
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float *__restrict__ part, float *__restrict__ dw,
+                                                         int64_t n, int nsplit, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int j = 0; j < nsplit; ++j) s += part[(size_t)j * n + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct TileGeom {
+  int NI, TP, IH_t, IW_t, logQ;
+  int ntiles;
+  bool ok;
+};
+
+// dynamic LDS above the 64 KiB default needs an explicit per-kernel opt-in
+template <typename F>
+inline void allow_lds(F fn, size_t bytes) {
+  if (bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// pixel tiling of an output of N x P x Q into tiles of `pixt` pixels; conv stride cs, filter R
+inline TileGeom make_geom(int N, int P, int Q, int pixt, int cs, int R) {
+  TileGeom g{};
+  g.ok = false;
+  if (Q <= 0 || (Q & (Q - 1)) != 0 || Q > pixt) return g;  // Q power of two, at most one tile wide
+  g.logQ = ilog2(Q);
+  const int PQ = P * Q;
+  if (PQ >= pixt) {
+    if (PQ % pixt != 0) return g;
+    g.NI = 1;
+    g.TP = pixt / Q;
+    g.ntiles = N * (PQ / pixt);
+  } else {
+    if (pixt % PQ != 0) return g;
+    g.NI = pixt / PQ;
+    g.TP = P;
+    g.ntiles = (N + g.NI - 1) / g.NI;
+  }
+  g.IH_t = (g.TP - 1) * cs + R;
+  g.IW_t = (Q - 1) * cs + R;
+  g.ok = (g.NI * g.IH_t * g.IW_t) <= 3 * 256;
+  return g;
+}
+
+template <int R, int STRIDE, bool DGRAD>
+int launch_igemm(const float *x, const float *w, const float *bias, float *y, int N, int xC, int xH, int xW, int yC,
+                 int yH, int yW, int pad, int wC, int wK, hipStream_t st) {
+  // tile shape: prefer 128 pixels x up to 128 channels; shrink when that leaves the chip under-filled
+  const int cs = DGRAD ? 1 : STRIDE;
+  int pixt = 128;
+  TileGeom g = make_geom(N, yH, yW, pixt, cs, R);
+  const int kblocks128 = (yC + 127) / 128;
+  if (!g.ok || g.ntiles * kblocks128 < 384) {
+    TileGeom g64 = make_geom(N, yH, yW, 64, cs, R);
+    if (g64.ok) { g = g64; pixt = 64; }
+  }
+  if (!g.ok) return SALUN_EINVAL;
+  const int PSZ = g.NI * g.IH_t * g.IW_t;
+  const int ch_stride = PSZ | 1;
+  constexpr int RS = R * R;
+#define SALUN_IGEMM(KT_, WP_, WK_)                                                                              \
+  {                                                                                                             \
+    constexpr int KB = WK_ * KT_ * 32;                                                                          \
+    const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));                  \
+    dim3 grid(g.ntiles, (yC + KB - 1) / KB);                                                                    \
+    allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD>, ldsb);                                               \
+    hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD>), grid, dim3(256), ldsb, st, x, w, bias, y, \
+                       N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK);             \
+  }
+  if (pixt == 128) {
+    if (yC > 64) SALUN_IGEMM(4, 4, 1)
+    else if (yC > 32) SALUN_IGEMM(2, 4, 1)
+    else SALUN_IGEMM(1, 4, 1)
+  } else {
+    // small pixel space (deep layers): 64 x 128 tiles only if that still yields enough workgroups
+    if (yC > 64 && g.ntiles * kblocks128 >= 384) SALUN_IGEMM(2, 2, 2)
+    else SALUN_IGEMM(1, 2, 2)
+  }
+#undef SALUN_IGEMM
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+inline int wgrad_nsplit(int K, int C, int nchunks) {
+  const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
+  int ns = (768 + tiles - 1) / tiles;
+  if (ns > nchunks) ns = nchunks;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+
+}  // namespace
+
+// ================================================================== C-ABI =======
+// y[N,K,P,Q] = conv2d(x[N,C,H,W], w[K,C,R,R], stride, pad_lo) (+ bias[K]); P,Q given by the caller
+// (so asymmetric high-side padding is expressed through P,Q).  Returns SALUN_EINVAL for shapes outside the
+// tiling's domain (Q not a power of two, ...): the caller then uses the library convolution.
+SALUN_EXPORT int salun_conv2d_forward(const float *x, const float *w, const float *bias, float *y, int N, int C,
+                                      int H, int W, int K, int R, int stride, int pad, int P, int Q,
+                                      salun_stream_t stream) {
+  if (!x || !w || !y || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  if (R == 3 && stride == 1) return launch_igemm<3, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
+  if (R == 3 && stride == 2) return launch_igemm<3, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
+  if (R == 1 && stride == 1) return launch_igemm<1, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
+  if (R == 1 && stride == 2) return launch_igemm<1, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
+  return SALUN_EINVAL;
+}
+
+// dx[N,C,H,W] = conv2d_backward_data(dy[N,K,P,Q], w[K,C,R,R])
+SALUN_EXPORT int salun_conv2d_backward_data(const float *dy, const float *w, float *dx, int N, int C, int H, int W,
+                                            int K, int R, int stride, int pad, int P, int Q,
+                                            salun_stream_t stream) {
+  if (!dy || !w || !dx || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  // patch source = dy (K channels, P x Q), output = dx (C channels, H x W)
+  if (R == 3 && stride == 1) return launch_igemm<3, 1, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
+  if (R == 3 && stride == 2) return launch_igemm<3, 2, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
+  if (R == 1 && stride == 1) return launch_igemm<1, 1, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
+  if (R == 1 && stride == 2) return launch_igemm<1, 2, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
+  return SALUN_EINVAL;
+}
+
+SALUN_EXPORT size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int R, int P, int Q) {
+  TileGeom g = make_geom(N, P, Q, 64, 1, R);
+  if (!g.ok) return 0;
+  const int ns = wgrad_nsplit(K, C, g.ntiles);
+  return sizeof(float) * (size_t)ns * K * C * R * R;
+}
+
+// dw[K,C,R,R] (= or +=) conv2d_backward_weight(x[N,C,H,W], dy[N,K,P,Q])
+SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, float *dw, int N, int C, int H, int W,
+                                              int K, int R, int stride, int pad, int P, int Q, int accumulate,
+                                              void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (!x || !dy || !dw || !ws || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
+  if (!((R == 3 || R == 1) && (stride == 1 || stride == 2))) return SALUN_EINVAL;
+  TileGeom g = make_geom(N, P, Q, 64, stride, R);
+  if (!g.ok) return SALUN_EINVAL;
+  const int ns = wgrad_nsplit(K, C, g.ntiles);
+  const size_t need = sizeof(float) * (size_t)ns * K * C * R * R;
+  if (ws_bytes < need) return SALUN_ENOSPC;
+  hipStream_t st = salun_hip_stream(stream);
+  const int PSZ = g.NI * g.IH_t * g.IW_t;
+  const size_t ldsb = sizeof(float) * ((size_t)64 * (PSZ | 1) + (size_t)64 * 65);
+  if (ldsb > 160 * 1024) return SALUN_EINVAL;
+  dim3 grid((K + 63) / 64, (C + 63) / 64, ns);
+  float *part = static_cast<float *>(ws);
+#define SALUN_WGRAD(R_, S_)                                                                                    \
+  allow_lds(conv_wgrad<R_, S_>, ldsb);                                                                         \
+  hipLaunchKernelGGL((conv_wgrad<R_, S_>), grid, dim3(256), ldsb, st, x, dy, part, N, C, H, W, K, P, Q, pad,   \
+                     g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles)
+  if (R == 3 && stride == 1) { SALUN_WGRAD(3, 1); }
+  else if (R == 3 && stride == 2) { SALUN_WGRAD(3, 2); }
+  else if (R == 1 && stride == 1) { SALUN_WGRAD(1, 1); }
+  else { SALUN_WGRAD(1, 2); }
+#undef SALUN_WGRAD
+  SALUN_LAUNCH_CHECK();
+  const int64_t n = (int64_t)K * C * R * R;
+  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(salun_grid_for(n, 256)), dim3(256), 0, st, part, dw, n, ns, accumulate);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}

@@ -210,6 +210,56 @@ def fim_square_accumulate(F: torch.Tensor, tmp: torch.Tensor, n_data: float) -> 
           "salun_fim_square_accumulate")
 
 
+# ----------------------------------------------------------------------------- K8
+def conv2d_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int, pad: int,
+                   P: int, Q: int) -> Optional[torch.Tensor]:
+    """y = conv2d(x, w) (+bias) on the matrix cores; None if the shape is outside the kernel's tiling domain."""
+    N, C, H, W = x.shape
+    K, _, R, _ = w.shape
+    y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().salun_conv2d_forward(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"),
+                                         _dev(bias, torch.float32, "bias", True), c_void_p(y.data_ptr()), N, C, H, W,
+                                         K, R, stride, pad, P, Q, _stream())
+    if rc == _lib.SALUN_EINVAL:
+        return None
+    check(rc, "salun_conv2d_forward")
+    return y
+
+
+def conv2d_backward_data(dy: torch.Tensor, w: torch.Tensor, x_shape, stride: int, pad: int) -> Optional[torch.Tensor]:
+    N, C, H, W = x_shape
+    K, _, R, _ = w.shape
+    P, Q = dy.shape[2], dy.shape[3]
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().salun_conv2d_backward_data(_dev(dy, torch.float32, "dy"), _dev(w, torch.float32, "w"),
+                                               c_void_p(dx.data_ptr()), N, C, H, W, K, R, stride, pad, P, Q,
+                                               _stream())
+    if rc == _lib.SALUN_EINVAL:
+        return None
+    check(rc, "salun_conv2d_backward_data")
+    return dx
+
+
+def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: int, pad: int
+                           ) -> Optional[torch.Tensor]:
+    N, C, H, W = x.shape
+    K, _, R, _ = w_shape
+    P, Q = dy.shape[2], dy.shape[3]
+    L = _lib.lib()
+    nbytes = L.salun_conv2d_wgrad_workspace_bytes(N, C, K, R, P, Q)
+    if nbytes == 0:
+        return None
+    ws = workspace(nbytes, x.device)
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    rc = L.salun_conv2d_backward_weight(_dev(x, torch.float32, "x"), _dev(dy, torch.float32, "dy"),
+                                        c_void_p(dw.data_ptr()), N, C, H, W, K, R, stride, pad, P, Q, 0,
+                                        c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream())
+    if rc == _lib.SALUN_EINVAL:
+        return None
+    check(rc, "salun_conv2d_backward_weight")
+    return dw
+
+
 # ----------------------------------------------------------------------------- K0
 def image_batch(data: torch.Tensor, idx: torch.Tensor, crop: Optional[torch.Tensor] = None,
                 flip: Optional[torch.Tensor] = None, pad: int = 4, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -16,6 +16,9 @@ LIB_PATH = os.path.join(_HERE, "libsalun.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 SALUN_OK = 0
+SALUN_EINVAL = -22
+SALUN_ENOSPC = -28
+SALUN_EIO = -5
 SALUN_MAX_THRESHOLDS = 16
 
 c_void_p, c_int, c_int64, c_uint64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64

@@ -82,19 +82,28 @@ def test_unsupported_shape_falls_back():
 
 
 def test_module_swap_resnet18_forward_backward():
+    """Whole-network check against a float64 CPU reference (direct convolution): the MFMA path must be within
+    fp32 round-off of it.  (The library path may use Winograd transforms, so it is not the yardstick.)"""
     from unlearn_saliency_amd.Classification.models import model_dict
     from unlearn_saliency_amd.conv import SalunConv2d, use_salun_convs
     torch.manual_seed(0)
-    ref = model_dict["resnet18"](num_classes=10).cuda()
-    mine = model_dict["resnet18"](num_classes=10).cuda()
+    ref = model_dict["resnet18"](num_classes=10)
+    mine = model_dict["resnet18"](num_classes=10)
     mine.load_state_dict(ref.state_dict())
+    mine.cuda()
     n = use_salun_convs(mine)
     assert n == 20 and isinstance(mine.conv1, SalunConv2d)
     assert list(mine.state_dict().keys()) == list(ref.state_dict().keys())
-    x = torch.rand(32, 3, 32, 32, device="cuda")
-    y = torch.randint(0, 10, (32,), device="cuda")
-    for m in (ref, mine):
-        m.train()
-        F.cross_entropy(m(x), y).backward()
+    x = torch.rand(16, 3, 32, 32)
+    y = torch.randint(0, 10, (16,))
+    ref.double().train()
+    F.cross_entropy(ref(x.double()), y).backward()
+    mine.train()
+    F.cross_entropy(mine(x.cuda()), y.cuda()).backward()
+    worst = 0.0
     for (k, p), q in zip(ref.named_parameters(), mine.parameters()):
-        assert torch.allclose(p.grad, q.grad, rtol=1e-3, atol=2e-4 * float(p.grad.abs().max())), k
+        scale = float(p.grad.abs().max())
+        err = float((p.grad.float() - q.grad.cpu()).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 2e-4, (k, err)
+    print("worst relative-to-scale gradient error vs float64:", worst)

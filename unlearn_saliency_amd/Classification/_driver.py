@@ -32,6 +32,9 @@ def run(argv=None, use_mask: bool = True):
     seed = args.seed
     model, train_loader_full, val_loader, test_loader, marked_loader = utils.setup_model_dataset(args)
     model.to(device)
+    if not args.library_conv:
+        from ..conv import use_salun_convs
+        use_salun_convs(model)  # convolutions on the fp32 MFMA kernels (csrc/salun_conv.hip)
     if ws > 1 and args.sync_bn:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
 

@@ -68,6 +68,8 @@ _BUILD_FLAGS = [
                              help="keep the uint8 dataset resident in HBM and assemble batches on the device")),
     ("--mask_ratio", dict(type=float, default=0.5, help="ratio read by RL_proximal (missing in the reference parser)")),
     ("--sync_bn", dict(action="store_true", help="SyncBatchNorm under multi-GPU data parallel")),
+    ("--library_conv", dict(action="store_true",
+                            help="use the library (MIOpen) convolutions instead of the fp32 MFMA kernels")),
     ("--thresholds", dict(type=str, default=None,
                           help="comma list of mask ratios for generate_mask (default: the reference's 0.1..1.0)")),
 ]

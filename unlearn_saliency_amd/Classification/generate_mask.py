@@ -112,6 +112,9 @@ def main(argv=None):
     seed = args.seed
     model, train_loader_full, val_loader, test_loader, marked_loader = utils.setup_model_dataset(args)
     model.to(device)
+    if not args.library_conv:
+        from ..conv import use_salun_convs
+        use_salun_convs(model)  # convolutions on the fp32 MFMA kernels (csrc/salun_conv.hip)
 
     def replace_loader_dataset(dataset, batch_size=args.batch_size, seed=1, shuffle=True):
         utils.setup_seed(seed)

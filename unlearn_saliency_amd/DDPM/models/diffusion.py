@@ -65,13 +65,19 @@ class Downsample(nn.Module):
     def __init__(self, channels, with_conv):
         super().__init__()
         self.with_conv = with_conv
+        self.use_mfma = False  # set by conv.use_salun_convs(model)
         if with_conv:
             self.conv = nn.Conv2d(channels, channels, 3, 2, 0)  # asymmetric (0,1,0,1) padding applied by hand
 
     def forward(self, x):
-        if self.with_conv:
-            return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
-        return F.avg_pool2d(x, 2, 2)
+        if not self.with_conv:
+            return F.avg_pool2d(x, 2, 2)
+        if (self.use_mfma and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+                and not torch.is_autocast_enabled()):
+            # the (0,1,0,1) zero padding is folded into the kernel: low-side pad 0, output size fixes the rest
+            from ...conv import conv2d_lowpad
+            return conv2d_lowpad(x, self.conv.weight, self.conv.bias, 2, 0, x.shape[2] // 2, x.shape[3] // 2)
+        return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
 
 
 class ResnetBlock(nn.Module):

@@ -109,6 +109,9 @@ class Diffusion(object):
         elif not getattr(args, "synthetic", False):
             raise FileNotFoundError(f"{path}: original-model checkpoint not found (pass --synthetic to benchmark "
                                     "a randomly initialised U-Net)")
+        if not getattr(args, "library_conv", False):
+            from ...conv import use_salun_convs
+            use_salun_convs(model)  # fp32 MFMA convolution kernels instead of the library's heuristics
         return model
 
     def _loaders(self):

@@ -48,6 +48,7 @@ _FLAGS = [
     # build extensions
     ("--synthetic", dict(action="store_true", help="random-init U-Net + synthetic CIFAR-shaped data (benchmarks)")),
     ("--n_iters", dict(type=int, default=None, help="override config.training.n_iters")),
+    ("--library_conv", dict(action="store_true", help="use the library (MIOpen) convolutions instead of the MFMA kernels")),
 ]
 
 

@@ -77,7 +77,13 @@ def use_salun_convs(model: nn.Module) -> int:
     """Re-class eligible nn.Conv2d modules in place.  Returns how many were switched."""
     n = 0
     for mod in model.modules():
-        if type(mod) is nn.Conv2d and _eligible(mod):
+        if hasattr(mod, "use_mfma") and hasattr(mod, "conv"):  # DDPM Downsample: asymmetric padding folded in
+            mod.use_mfma = True
+            n += 1
+            continue
+    owners = {id(m.conv) for m in model.modules() if getattr(m, "use_mfma", False) and hasattr(m, "conv")}
+    for mod in model.modules():
+        if type(mod) is nn.Conv2d and _eligible(mod) and id(mod) not in owners:
             mod.__class__ = SalunConv2d
             n += 1
     return n

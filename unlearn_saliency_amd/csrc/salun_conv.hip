@@ -132,42 +132,68 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
   const int Cred = xC;  // reduction channels = channels of the tensor the patch is read from
-  for (int c0 = 0; c0 < Cred; c0 += CC) {
-    __syncthreads();  // previous chunk fully consumed
-    // ---- stage the input patch: CC channels x PSZ positions
+  // Register-staged software pipeline: the global loads of chunk i+1 are issued before the MFMA section of
+  // chunk i and only consumed (written to LDS) after it, so their latency hides under the matrix work.
+  constexpr int WN = KB * CC * RS / 256;  // weight-slab elements per thread per chunk (KB*RS/32)
+  float preg[MAXPOS][CC];
+  float wreg[WN];
+
+  auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int j = 0; j < MAXPOS; ++j) {
-      if (pos[j].loff < PSZ) {
 #pragma unroll
-        for (int c = 0; c < CC; ++c) {
-          float v = 0.f;
-          if (pos[j].valid && (c0 + c) < Cred) v = x[pos[j].goff + (c0 + c) * planeHW];
-          patch[c * ch_stride + pos[j].loff] = v;
-        }
+      for (int c = 0; c < CC; ++c) {
+        float v = 0.f;
+        if (pos[j].valid && (c0 + c) < Cred) v = x[pos[j].goff + (c0 + c) * planeHW];
+        preg[j][c] = v;
       }
     }
-    // ---- stage the weight slab wl[kk][c*RS + rs] for kk < KB, c < CC
-    if (!DGRAD) {
-      // forward: rows = output channel k, global w[k][c0..c0+CC][rs] is one contiguous run per k
-      for (int e = tid; e < KB * CC * RS; e += 256) {
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int e = tid + i * 256;
+      float v = 0.f;
+      if (!DGRAD) {
+        // forward: rows = output channel k; global w[k][c0..c0+CC][rs] is one contiguous run per k
         const int kk = e / (CC * RS), j = e - kk * (CC * RS);
         const int c = j / RS;
-        float v = 0.f;
         if ((k0 + kk) < wK && (c0 + c) < wC) v = w[(size_t)(k0 + kk) * wC * RS + (size_t)c0 * RS + j];
-        wl[kk * WROW + j] = v;
-      }
-    } else {
-      // backward-data: rows = input channel c of the forward conv (output of this pass), reduction over forward k;
-      // global w[k][c][rs] is contiguous over (c, rs) for a fixed k; taps are flipped while staging
-      for (int e = tid; e < CC * KB * RS; e += 256) {
-        const int kk = e / (KB * RS), rem = e - kk * (KB * RS);  // kk: reduction index (forward k) inside the chunk
-        const int cl = rem / RS, rs = rem - cl * RS;             // cl: output row (forward c) inside the tile
-        float v = 0.f;
+      } else {
+        // backward-data: rows = forward input channel (output of this pass), reduction over forward k;
+        // global w[k][c][rs] is contiguous over (c, rs) for a fixed k
+        const int kk = e / (KB * RS), rem = e - kk * (KB * RS);
+        const int cl = rem / RS, rs = rem - cl * RS;
         if ((c0 + kk) < wK && (k0 + cl) < wC) v = w[(size_t)(c0 + kk) * wC * RS + (size_t)(k0 + cl) * RS + rs];
-        wl[cl * WROW + kk * RS + (RS - 1 - rs)] = v;
+      }
+      wreg[i] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int j = 0; j < MAXPOS; ++j)
+      if (pos[j].loff < PSZ) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) patch[c * ch_stride + pos[j].loff] = preg[j][c];
+      }
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int e = tid + i * 256;
+      if (!DGRAD) {
+        const int kk = e / (CC * RS), j = e - kk * (CC * RS);
+        wl[kk * WROW + j] = wreg[i];
+      } else {
+        const int kk = e / (KB * RS), rem = e - kk * (KB * RS);
+        const int cl = rem / RS, rs = rem - cl * RS;
+        wl[cl * WROW + kk * RS + (RS - 1 - rs)] = wreg[i];  // taps flipped while staging
       }
     }
+  };
+
+  load_chunk(0);
+  for (int c0 = 0; c0 < Cred; c0 += CC) {
+    __syncthreads();  // previous chunk fully consumed
+    store_chunk();
     __syncthreads();
+    if (c0 + CC < Cred) load_chunk(c0 + CC);  // in flight during the MFMA section below
     // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1)
 #pragma unroll
     for (int cc = 0; cc < CC; cc += 2) {
@@ -285,7 +311,8 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
           acc[r * R + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[r * IW_t + s], acc[r * R + s], 0, 0, 0);
     }
   }
-  // ---- partial[split][k][c][rs]
+  // ---- partial[split][rs][k][c]: a wave's 32 result columns (c) are contiguous => coalesced 128-B stores;
+  // the reduce kernel maps back to OIHW
   float *out = part + (size_t)split * K * C * RS;
   const int c = c0 + ct * 32 + lo;
   if (c < C) {
@@ -294,18 +321,33 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int k = k0 + kt * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
-        if (k < K) out[((size_t)k * C + c) * RS + t] = acc[t][v];
+        if (k < K) out[((size_t)t * K + k) * C + c] = acc[t][v];
       }
   }
 }
 
-// dw[i] (+)= sum_s part[s][i], fixed order
+// dw (+)= sum_s part[s] in a fixed order: 8 strided sub-sums per output (thread g sums s = g, g+8, ...), folded
+// g = 0..7 through LDS.  32 outputs x 8 groups per workgroup keeps thousands of waves with loads in flight instead
+// of one long serial chain per output.  Partials are [rs][k][c]; the result is written in OIHW.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float *__restrict__ part, float *__restrict__ dw,
-                                                         int64_t n, int nsplit, int accumulate) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int j = 0; j < nsplit; ++j) s += part[(size_t)j * n + i];
-    dw[i] = accumulate ? dw[i] + s : s;
+                                                         int64_t n, int nsplit, int accumulate, int KC, int RS) {
+  __shared__ float red[8][33];
+  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + o;  // index in [rs][k][c] order
+  float s = 0.f;
+  if (i < n) {
+#pragma unroll 8
+    for (int j = g; j < nsplit; j += 8) s += part[(size_t)j * n + i];
+  }
+  red[g][o] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float t = red[0][o];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][o];
+    const int64_t rs = i / KC, kc = i - rs * KC;
+    const int64_t dst = kc * RS + rs;
+    dw[dst] = accumulate ? dw[dst] + t : t;
   }
 }
 
@@ -319,8 +361,16 @@ struct TileGeom {
 // dynamic LDS above the 64 KiB default needs an explicit per-kernel opt-in
 template <typename F>
 inline void allow_lds(F fn, size_t bytes) {
-  if (bytes > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  // once per kernel instantiation and size class: the attribute call is a driver round trip
+  static size_t granted = 0;  // one static per template instantiation F... (F is the function pointer type, so
+                              // key on the pointer value as well)
+  static const void *granted_fn = nullptr;
+  if (bytes > 48 * 1024 && (granted_fn != reinterpret_cast<const void *>(fn) || bytes > granted)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    granted = 160 * 1024;
+    granted_fn = reinterpret_cast<const void *>(fn);
+  }
 }
 
 inline int ilog2(int v) {
@@ -467,7 +517,8 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
 #undef SALUN_WGRAD
   SALUN_LAUNCH_CHECK();
   const int64_t n = (int64_t)K * C * R * R;
-  hipLaunchKernelGGL(conv_wgrad_reduce, dim3(salun_grid_for(n, 256)), dim3(256), 0, st, part, dw, n, ns, accumulate);
+  hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, dw, n, ns, accumulate,
+                     K * C, R * R);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }

@@ -21,6 +21,8 @@
 //   9 accumulators (one per tap) per wave, pixel range split over workgroups -> partials -> fixed-order reduce
 //   (deterministic, no float atomics).
 #include "salun_common.h"
+#include <mutex>
+#include <unordered_set>
 
 namespace {
 
@@ -358,19 +360,18 @@ struct TileGeom {
   bool ok;
 };
 
-// dynamic LDS above the 64 KiB default needs an explicit per-kernel opt-in
+// dynamic LDS above the default limit needs a per-kernel opt-in; the attribute call is a slow driver round trip,
+// so it is made once per kernel (process-wide table, the only mutable global state of the library).
+inline void allow_lds_once(const void *fn) {
+  static std::mutex mu;
+  static std::unordered_set<const void *> done;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert(fn).second)
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 template <typename F>
 inline void allow_lds(F fn, size_t bytes) {
-  // once per kernel instantiation and size class: the attribute call is a driver round trip
-  static size_t granted = 0;  // one static per template instantiation F... (F is the function pointer type, so
-                              // key on the pointer value as well)
-  static const void *granted_fn = nullptr;
-  if (bytes > 48 * 1024 && (granted_fn != reinterpret_cast<const void *>(fn) || bytes > granted)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    granted = 160 * 1024;
-    granted_fn = reinterpret_cast<const void *>(fn);
-  }
+  if (bytes > 48 * 1024) allow_lds_once(reinterpret_cast<const void *>(fn));
 }
 
 inline int ilog2(int v) {

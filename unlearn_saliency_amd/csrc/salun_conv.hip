@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
                                                   int Q, int pad, int NI, int TP, int IH_t, int IW_t, int logQ,
                                                   int nchunks) {
   constexpr int RS = R * R;
-  constexpr int PIXC = 64;  // pixels per chunk
+  constexpr int PIXC = (STRIDE == 1) ? 64 : 32;  // pixels per chunk (stride 2: 32, so the patch stays <= 256 floats)
   constexpr int DROW = PIXC + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int PSZ = NI * IH_t * IW_t;
@@ -265,38 +265,64 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
-  for (int chunk = split; chunk < nchunks; chunk += nsplit) {
+  // Register-staged software pipeline (as in conv_igemm): chunk i+1 is fetched from global memory while the
+  // matrix cores work on chunk i.
+  // one patch position per thread (PSZ <= 256 by construction of PIXC): 64 channel values + the dy slice
+  float xreg[64];
+  constexpr int DN = 64 * PIXC / 256;
+  float dreg[DN];
+  constexpr int LOGPIX = (PIXC == 64) ? 6 : 5;
+
+  auto load_chunk = [&](int chunk) {
     int n0, p0;
     if (NI > 1) { n0 = chunk * NI; p0 = 0; }
     else { n0 = chunk / tiles_per_img; p0 = (chunk - n0 * tiles_per_img) * TP; }
-    __syncthreads();
-    // ---- stage x patch: 64 channels x PSZ positions (zero padded)
-    for (int e = tid; e < PSZ; e += 256) {
+    {
+      const int e = tid;
       const int ni = e / (IH_t * IW_t);
       const int rem = e - ni * (IH_t * IW_t);
       const int ih = rem / IW_t, iw = rem - ih * IW_t;
       const int n = n0 + ni;
       const int h = p0 * STRIDE - pad + ih, ww = -pad + iw;
-      const bool ok = (n < N) && h >= 0 && h < H && ww >= 0 && ww < W;
-      const size_t g = ok ? ((size_t)n * C * planeHW + (size_t)h * W + ww) : 0;
-#pragma unroll 8
+      const bool ok = (e < PSZ) && (n < N) && h >= 0 && h < H && ww >= 0 && ww < W;
+      const float *src = x + (ok ? ((size_t)n * C * planeHW + (size_t)h * W + ww) : 0) + (size_t)c0 * planeHW;
+      const int cvalid = ok ? (C - c0) : 0;  // channels c < cvalid are real
+#pragma unroll
       for (int c = 0; c < 64; ++c) {
-        float v = 0.f;
-        if (ok && (c0 + c) < C) v = x[g + (size_t)(c0 + c) * planeHW];
-        xp[c * ch_stride + e] = v;
+        xreg[c] = (c < cvalid) ? *src : 0.f;
+        src += planeHW;
       }
     }
-    // ---- stage dy tile: 64 k x 64 pixels
-    for (int e = tid; e < 64 * PIXC; e += 256) {
-      const int kk = e >> 6, m = e & 63;
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      const int e = tid + i * 256;
+      const int kk = e >> LOGPIX, m = e & (PIXC - 1);
       const int q = m & (Q - 1), pr = m >> logQ;
       const int ni = pr / TP, pl = pr - ni * TP;
       const int n = n0 + ni;
       float v = 0.f;
       if (n < N && (k0 + kk) < K) v = dy[((size_t)n * K + (k0 + kk)) * PQ + (size_t)(p0 + pl) * Q + q];
-      dl[kk * DROW + m] = v;
+      dreg[i] = v;
     }
+  };
+  auto store_chunk = [&]() {
+    if (tid < PSZ) {
+#pragma unroll
+      for (int c = 0; c < 64; ++c) xp[c * ch_stride + tid] = xreg[c];
+    }
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      const int e = tid + i * 256;
+      dl[(e >> LOGPIX) * DROW + (e & (PIXC - 1))] = dreg[i];
+    }
+  };
+
+  if (split < nchunks) load_chunk(split);
+  for (int chunk = split; chunk < nchunks; chunk += nsplit) {
     __syncthreads();
+    store_chunk();
+    __syncthreads();
+    if (chunk + nsplit < nchunks) load_chunk(chunk + nsplit);
     const float *arow = dl + (kt * 32 + lo) * DROW;
     const float *brow = xp + (ct * 32 + lo) * ch_stride;
 #pragma unroll 4
@@ -484,7 +510,9 @@ SALUN_EXPORT int salun_conv2d_backward_data(const float *dy, const float *w, flo
 }
 
 SALUN_EXPORT size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int R, int P, int Q) {
-  TileGeom g = make_geom(N, P, Q, 64, 1, R);
+  // upper bound over both chunk sizes (64 pixels for stride 1, 32 for stride 2)
+  TileGeom g = make_geom(N, P, Q, 32, 1, R);
+  if (!g.ok) g = make_geom(N, P, Q, 64, 1, R);
   if (!g.ok) return 0;
   const int ns = wgrad_nsplit(K, C, g.ntiles);
   return sizeof(float) * (size_t)ns * K * C * R * R;
@@ -496,14 +524,15 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
                                               void *ws, size_t ws_bytes, salun_stream_t stream) {
   if (!x || !dy || !dw || !ws || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
   if (!((R == 3 || R == 1) && (stride == 1 || stride == 2))) return SALUN_EINVAL;
-  TileGeom g = make_geom(N, P, Q, 64, stride, R);
-  if (!g.ok) return SALUN_EINVAL;
+  const int pixc = (stride == 1) ? 64 : 32;
+  TileGeom g = make_geom(N, P, Q, pixc, stride, R);
+  if (!g.ok || g.NI * g.IH_t * g.IW_t > 256) return SALUN_EINVAL;
   const int ns = wgrad_nsplit(K, C, g.ntiles);
   const size_t need = sizeof(float) * (size_t)ns * K * C * R * R;
   if (ws_bytes < need) return SALUN_ENOSPC;
   hipStream_t st = salun_hip_stream(stream);
   const int PSZ = g.NI * g.IH_t * g.IW_t;
-  const size_t ldsb = sizeof(float) * ((size_t)64 * (PSZ | 1) + (size_t)64 * 65);
+  const size_t ldsb = sizeof(float) * ((size_t)64 * (PSZ | 1) + (size_t)64 * (pixc + 1));
   if (ldsb > 160 * 1024) return SALUN_EINVAL;
   dim3 grid((K + 63) / 64, (C + 63) / 64, ns);
   float *part = static_cast<float *>(ws);

@@ -218,6 +218,8 @@ def main():
     # the optimizer tail on the launch stream: at N=1 exactly one kernel (salun_masked_sgd_step)
     tail_ms = sorted(s.elapsed_time(e) for s, e in events)
     tail_mean_s = 1e-3 * sum(tail_ms) / len(tail_ms)
+    # per-step device time from consecutive event timestamps (shows clock/thermal drift over the run)
+    step_ms = [events[i][0].elapsed_time(events[i + 1][0]) for i in range(len(events) - 1)]
 
     if rank == 0:
         steps_per_s = a.steps * world / dt
@@ -236,6 +238,9 @@ def main():
             "samples_per_sec": steps_per_s * a.batch_size,
             "mask_gen_sec": None if mask_gen is None else mask_gen["total_sec"],
             "mask_gen": mask_gen,
+            "step_ms_trend": {"first5": [round(v, 2) for v in step_ms[:5]], "last5": [round(v, 2) for v in step_ms[-5:]],
+                              "min": round(min(step_ms), 2) if step_ms else None,
+                              "max": round(max(step_ms), 2) if step_ms else None},
             "roofline": {"kernel": "salun_masked_sgd_step" + ("" if world == 1 else " (+ flat-gradient all-reduce)"),
                          "bound": "hbm", "achieved": alg_bytes / tail_mean_s / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / tail_mean_s / 1e9 / HBM_PEAK_GBS, "traffic": None,

@@ -199,6 +199,18 @@ def main():
         if ev is not None:
             ev[1].record()
 
+    # untimed preparation: both uint8 sets resident in HBM, and one step at each ragged tail-batch size of the
+    # reference's epoch (4500 % 256 = 148 forget, 40500 % 256 = 52 retain) so shape-specialised library state
+    # (BN / GEMM heuristics) exists before the clock starts
+    for ld in (forget_loader, retain_loader):
+        ld._resident()
+    for tail in sorted({len(forget_loader.dataset) % (a.batch_size * world) // world,
+                        len(retain_loader.dataset) % (a.batch_size * world) // world} - {0}):
+        xs = torch.rand(tail, 3, 32, 32, device=device)
+        ys = torch.randint(0, 10, (tail,), device=device)
+        opt.zero_grad()
+        criterion(model(xs), ys).backward()
+        arena.zero_grad()  # discard: no parameter update from the shape warm-up
     for _ in range(a.warmup):
         one_step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]

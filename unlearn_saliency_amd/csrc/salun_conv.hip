@@ -145,28 +145,33 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
     for (int j = 0; j < MAXPOS; ++j) {
 #pragma unroll
       for (int c = 0; c < CC; ++c) {
-        float v = 0.f;
-        if (pos[j].valid && (c0 + c) < Cred) v = x[pos[j].goff + (c0 + c) * planeHW];
-        preg[j][c] = v;
+        // unconditional load from a clamped (always in-bounds) address + select: no divergent branch per load
+        const bool ok = pos[j].valid && (c0 + c) < Cred;
+        const float t = x[pos[j].goff + (ok ? (c0 + c) : 0) * planeHW];
+        preg[j][c] = ok ? t : 0.f;
       }
     }
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
       const int e = tid + i * 256;
-      float v = 0.f;
+      bool ok;
+      int off;
       if (!DGRAD) {
         // forward: rows = output channel k; global w[k][c0..c0+CC][rs] is one contiguous run per k
         const int kk = e / (CC * RS), j = e - kk * (CC * RS);
         const int c = j / RS;
-        if ((k0 + kk) < wK && (c0 + c) < wC) v = w[(size_t)(k0 + kk) * wC * RS + (size_t)c0 * RS + j];
+        ok = (k0 + kk) < wK && (c0 + c) < wC;
+        off = (k0 + kk) * wC * RS + c0 * RS + j;
       } else {
         // backward-data: rows = forward input channel (output of this pass), reduction over forward k;
         // global w[k][c][rs] is contiguous over (c, rs) for a fixed k
         const int kk = e / (KB * RS), rem = e - kk * (KB * RS);
         const int cl = rem / RS, rs = rem - cl * RS;
-        if ((c0 + kk) < wK && (k0 + cl) < wC) v = w[(size_t)(c0 + kk) * wC * RS + (size_t)(k0 + cl) * RS + rs];
+        ok = (c0 + kk) < wK && (k0 + cl) < wC;
+        off = (c0 + kk) * wC * RS + (k0 + cl) * RS + rs;
       }
-      wreg[i] = v;
+      const float t = w[ok ? off : 0];  // clamped address, unconditional load
+      wreg[i] = ok ? t : 0.f;
     }
   };
   auto store_chunk = [&]() {
@@ -196,22 +201,34 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
     store_chunk();
     __syncthreads();
     if (c0 + CC < Cred) load_chunk(c0 + CC);  // in flight during the MFMA section below
-    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1)
-#pragma unroll
-    for (int cc = 0; cc < CC; cc += 2) {
+    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1).
+    // Operands are double-buffered in registers: the LDS reads of channel pair i+1 are issued (and fenced by a
+    // scheduling barrier) before the R*S*KT MFMAs of pair i, so no MFMA waits on an LDS round trip.
+    float bq[2][RS], aq[2][KT][RS];
+    auto lds_operands = [&](int buf, int cc) {
       const float *pbase = patch + (cc + hi) * ch_stride + pix_off;
       const float *wbase = wl + (wk * KT * 32 + lo) * WROW + (cc + hi) * RS;
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int s = 0; s < R; ++s) {
-          const float b = pbase[r * IW_t + s];
+        for (int s2 = 0; s2 < R; ++s2) {
+          bq[buf][r * R + s2] = pbase[r * IW_t + s2];
 #pragma unroll
-          for (int t = 0; t < KT; ++t) {
-            const float a = wbase[t * 32 * WROW + r * R + s];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-          }
+          for (int t = 0; t < KT; ++t) aq[buf][t][r * R + s2] = wbase[t * 32 * WROW + r * R + s2];
         }
+    };
+    lds_operands(0, 0);
+#pragma unroll
+    for (int cc = 0; cc < CC; cc += 2) {
+      const int cur = (cc >> 1) & 1;
+      if (cc + 2 < CC) lds_operands(cur ^ 1, cc + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rs = 0; rs < RS; ++rs)
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][t][rs], bq[cur][rs], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -285,12 +302,13 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
       const int n = n0 + ni;
       const int h = p0 * STRIDE - pad + ih, ww = -pad + iw;
       const bool ok = (e < PSZ) && (n < N) && h >= 0 && h < H && ww >= 0 && ww < W;
-      const float *src = x + (ok ? ((size_t)n * C * planeHW + (size_t)h * W + ww) : 0) + (size_t)c0 * planeHW;
+      const float *src = x + (ok ? ((size_t)n * C * planeHW + (size_t)h * W + ww + (size_t)c0 * planeHW) : 0);
       const int cvalid = ok ? (C - c0) : 0;  // channels c < cvalid are real
 #pragma unroll
       for (int c = 0; c < 64; ++c) {
-        xreg[c] = (c < cvalid) ? *src : 0.f;
-        src += planeHW;
+        const bool okc = c < cvalid;
+        const float t = src[okc ? (size_t)c * planeHW : 0];  // clamped address, unconditional load
+        xreg[c] = okc ? t : 0.f;
       }
     }
 #pragma unroll
@@ -300,9 +318,9 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
       const int q = m & (Q - 1), pr = m >> logQ;
       const int ni = pr / TP, pl = pr - ni * TP;
       const int n = n0 + ni;
-      float v = 0.f;
-      if (n < N && (k0 + kk) < K) v = dy[((size_t)n * K + (k0 + kk)) * PQ + (size_t)(p0 + pl) * Q + q];
-      dreg[i] = v;
+      const bool okd = n < N && (k0 + kk) < K;
+      const float t = dy[okd ? (((size_t)n * K + (k0 + kk)) * PQ + (size_t)(p0 + pl) * Q + q) : 0];
+      dreg[i] = okd ? t : 0.f;
     }
   };
   auto store_chunk = [&]() {

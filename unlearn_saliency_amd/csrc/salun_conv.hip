@@ -201,34 +201,22 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
     store_chunk();
     __syncthreads();
     if (c0 + CC < Cred) load_chunk(c0 + CC);  // in flight during the MFMA section below
-    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1).
-    // Operands are double-buffered in registers: the LDS reads of channel pair i+1 are issued (and fenced by a
-    // scheduling barrier) before the R*S*KT MFMAs of pair i, so no MFMA waits on an LDS round trip.
-    float bq[2][RS], aq[2][KT][RS];
-    auto lds_operands = [&](int buf, int cc) {
+    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1)
+#pragma unroll
+    for (int cc = 0; cc < CC; cc += 2) {
       const float *pbase = patch + (cc + hi) * ch_stride + pix_off;
       const float *wbase = wl + (wk * KT * 32 + lo) * WROW + (cc + hi) * RS;
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int s2 = 0; s2 < R; ++s2) {
-          bq[buf][r * R + s2] = pbase[r * IW_t + s2];
+          const float b = pbase[r * IW_t + s2];
 #pragma unroll
-          for (int t = 0; t < KT; ++t) aq[buf][t][r * R + s2] = wbase[t * 32 * WROW + r * R + s2];
+          for (int t = 0; t < KT; ++t) {
+            const float a = wbase[t * 32 * WROW + r * R + s2];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+          }
         }
-    };
-    lds_operands(0, 0);
-#pragma unroll
-    for (int cc = 0; cc < CC; cc += 2) {
-      const int cur = (cc >> 1) & 1;
-      if (cc + 2 < CC) lds_operands(cur ^ 1, cc + 2);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int rs = 0; rs < RS; ++rs)
-#pragma unroll
-        for (int t = 0; t < KT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][t][rs], bq[cur][rs], acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

@@ -30,7 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CC = 8;  // reduction channels staged per chunk
 
-struct ConvGeom {
+struct ConvGeomUnused {
   // logical convolution: out[n][k][p][q] = sum x[n][c][p*S - pad + r][q*S - pad + s] * w[k][c][r][s]
   int N, C, H, W, K, P, Q, pad;
   // tile decomposition of the output pixel space (n, p, q), q fastest
@@ -51,58 +51,66 @@ struct PatchPos {
 
 // ---------------------------------------------------------------------------------------------------
 // forward / backward-data
-//   R        filter size (1 or 3), square
-//   STRIDE   forward: convolution stride; DGRAD: upsampling factor of dY (conv stride is 1)
+//   RH x RW  taps staged per channel (forward: the full R x R filter; backward-data with stride 2: the 1..2 x 1..2
+//            taps that reach one output parity class)
+//   STRIDE   forward convolution stride (backward-data always walks its source with stride 1)
 //   KT       32-channel output tiles per wave
 //   WP x WK  wave grid inside the workgroup: WP pixel tiles x WK channel groups (WP*WK == 4)
-//   DGRAD    backward-data mode
-// `x` is the tensor the patch is read from (forward: input; DGRAD: dY), `y` the tensor written.
-// `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
-// STRIDE and the padding is R-1-pad.
-template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD>
-__global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
-                                                  const float *__restrict__ bias, float *__restrict__ y, int N,
-                                                  int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
-                                                  int TP, int IH_t, int IW_t, int logQ, int wC /*w dim1 (C of OIHW)*/,
-                                                  int wK /*w dim0*/) {
-  constexpr int RS = R * R;
-  constexpr int PIXT = WP * 32;        // pixels per workgroup tile
+//   DGRAD    backward-data mode: source = dY, weight slab transposed, taps taken as r_i = rtop - ts*i
+// Backward-data of a stride-2 convolution is decomposed by output parity (ph, pw): dx[2a+ph][2b+pw] only receives
+// taps r = (ph + pad) mod 2 (+2), so each class is a small dense stride-1 convolution over dY written to a
+// strided sub-grid of dx — same FLOPs as the forward pass, no zero-insertion.
+struct IgemmArgs {
+  const float *x;     // tensor the patch is read from (forward: input; DGRAD: dY)
+  const float *w;     // OIHW weights [wK][wC][Rfull][Rfull]
+  const float *bias;  // optional, per output channel
+  float *y;           // tensor written (forward: output; DGRAD: dX)
+  int N, xC, xH, xW, yC, yH, yW;
+  int subH, subW;          // output sub-grid walked by the tiles (yH/os, yW/os)
+  int os, ph, pw;          // output position = sub * os + (ph, pw)
+  int vpad_h, vpad_w;      // patch origin: source row = p0*conv_stride - vpad_h + ih
+  int NI, TP, IH_t, IW_t, logQ;
+  int wC, wK, Rfull;
+  int rtop_h, rtop_w, ts;  // DGRAD tap mapping
+};
+
+template <int RH, int RW, int STRIDE, int KT, int WP, int WK, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_igemm(const IgemmArgs g) {
+  constexpr int RS = RH * RW;
   constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
   constexpr int WROW = CC * RS + 1;    // LDS weight row (odd => conflict-free across 32 rows)
   constexpr int CONV_S = DGRAD ? 1 : STRIDE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int NI = g.NI, TP = g.TP, IH_t = g.IH_t, IW_t = g.IW_t;
   const int PSZ = NI * IH_t * IW_t;
   const int ch_stride = PSZ | 1;
   float *patch = lds;                   // [CC][ch_stride]
   float *wl = lds + CC * ch_stride;     // [KB][WROW]
+  const float *__restrict__ x = g.x;
+  const float *__restrict__ w = g.w;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 31, hi = lane >> 5;
   const int wp = wave % WP, wk = wave / WP;
-  const int Q = yW, P = yH;
-  const int tiles_per_img = (P * Q) / (TP * Q);  // row bands per image (1 when NI >= 1 image)
+  const int Q = g.subW, P = g.subH;
+  const int tiles_per_img = P / TP;  // row bands per image (1 when a tile spans whole images)
   const int tile = blockIdx.x;
   const int k0 = blockIdx.y * KB;
-  // tile -> first image / first output row
   int n0, p0;
   if (NI > 1) { n0 = tile * NI; p0 = 0; }
   else { n0 = tile / tiles_per_img; p0 = (tile - n0 * tiles_per_img) * TP; }
 
   // ---- this lane's output pixel inside the tile (fixed for the whole kernel)
-  const int mloc = wp * 32 + lo;               // 0..PIXT-1
+  const int mloc = wp * 32 + lo;
   const int q_l = mloc & (Q - 1);
-  const int pr = mloc >> logQ;                 // row index inside the tile (over NI*TP rows)
+  const int pr = mloc >> g.logQ;               // row index inside the tile (over NI*TP rows)
   const int ni_l = pr / TP, p_l = pr - ni_l * TP;
   const int pix_off = (ni_l * IH_t + p_l * CONV_S) * IW_t + q_l * CONV_S;  // tap (0,0) position in the patch
 
   // ---- the (<= 3) patch positions this thread stages for every channel of a chunk
   constexpr int MAXPOS = 3;
   PatchPos pos[MAXPOS];
-  const int planeHW = xH * xW;
-  // virtual (possibly upsampled) input extent
-  const int vH = DGRAD ? (xH - 1) * STRIDE + 1 : xH;
-  const int vW = DGRAD ? (xW - 1) * STRIDE + 1 : xW;
-  const int vpad = DGRAD ? (R - 1 - pad) : pad;
+  const int xC = g.xC, planeHW = g.xH * g.xW;
 #pragma unroll
   for (int j = 0; j < MAXPOS; ++j) {
     const int e = tid + j * 256;
@@ -114,16 +122,10 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
       const int rem = e - ni * (IH_t * IW_t);
       const int ih = rem / IW_t, iw = rem - ih * IW_t;
       const int n = n0 + ni;
-      const int vh = p0 * CONV_S - vpad + ih, vw = -vpad + iw;
-      bool ok = (n < N) && vh >= 0 && vh < vH && vw >= 0 && vw < vW;
-      int sh = vh, sw = vw;
-      if (DGRAD && STRIDE > 1) {
-        ok = ok && (vh % STRIDE == 0) && (vw % STRIDE == 0);
-        sh = vh / STRIDE;
-        sw = vw / STRIDE;
-      }
+      const int vh = p0 * CONV_S - g.vpad_h + ih, vw = -g.vpad_w + iw;
+      const bool ok = (n < g.N) && vh >= 0 && vh < g.xH && vw >= 0 && vw < g.xW;
       pos[j].valid = ok;
-      pos[j].goff = ok ? (n * xC * planeHW + sh * xW + sw) : 0;
+      pos[j].goff = ok ? (n * xC * planeHW + vh * g.xW + vw) : 0;
     }
   }
 
@@ -134,9 +136,10 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
   const int Cred = xC;  // reduction channels = channels of the tensor the patch is read from
+  const int wC = g.wC, wK = g.wK, RF2 = g.Rfull * g.Rfull;
   // Register-staged software pipeline: the global loads of chunk i+1 are issued before the MFMA section of
   // chunk i and only consumed (written to LDS) after it, so their latency hides under the matrix work.
-  constexpr int WN = KB * CC * RS / 256;  // weight-slab elements per thread per chunk (KB*RS/32)
+  constexpr int WN = KB * CC * RS / 256;  // weight-slab elements per thread per chunk
   float preg[MAXPOS][CC];
   float wreg[WN];
 
@@ -145,10 +148,9 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
     for (int j = 0; j < MAXPOS; ++j) {
 #pragma unroll
       for (int c = 0; c < CC; ++c) {
-        // unconditional load from a clamped (always in-bounds) address + select: no divergent branch per load
-        const bool ok = pos[j].valid && (c0 + c) < Cred;
-        const float t = x[pos[j].goff + (ok ? (c0 + c) : 0) * planeHW];
-        preg[j][c] = ok ? t : 0.f;
+        float v = 0.f;
+        if (pos[j].valid && (c0 + c) < Cred) v = x[pos[j].goff + (c0 + c) * planeHW];
+        preg[j][c] = v;
       }
     }
 #pragma unroll
@@ -163,15 +165,16 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
         ok = (k0 + kk) < wK && (c0 + c) < wC;
         off = (k0 + kk) * wC * RS + c0 * RS + j;
       } else {
-        // backward-data: rows = forward input channel (output of this pass), reduction over forward k;
-        // global w[k][c][rs] is contiguous over (c, rs) for a fixed k
+        // backward-data: rows = forward input channel (output of this pass), reduction over forward k
         const int kk = e / (KB * RS), rem = e - kk * (KB * RS);
-        const int cl = rem / RS, rs = rem - cl * RS;
+        const int cl = rem / RS, t = rem - cl * RS;
+        const int ti = t / RW, tj = t - ti * RW;
         ok = (c0 + kk) < wK && (k0 + cl) < wC;
-        off = (c0 + kk) * wC * RS + (k0 + cl) * RS + rs;
+        off = ((c0 + kk) * wC + (k0 + cl)) * RF2 + (g.rtop_h - g.ts * ti) * g.Rfull + (g.rtop_w - g.ts * tj);
       }
-      const float t = w[ok ? off : 0];  // clamped address, unconditional load
-      wreg[i] = ok ? t : 0.f;
+      float v = 0.f;
+      if (ok) v = w[off];
+      wreg[i] = v;
     }
   };
   auto store_chunk = [&]() {
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
         wl[kk * WROW + j] = wreg[i];
       } else {
         const int kk = e / (KB * RS), rem = e - kk * (KB * RS);
-        const int cl = rem / RS, rs = rem - cl * RS;
-        wl[cl * WROW + kk * RS + (RS - 1 - rs)] = wreg[i];  // taps flipped while staging
+        const int cl = rem / RS, t = rem - cl * RS;
+        wl[cl * WROW + kk * RS + t] = wreg[i];
       }
     }
   };
@@ -207,13 +210,13 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
       const float *pbase = patch + (cc + hi) * ch_stride + pix_off;
       const float *wbase = wl + (wk * KT * 32 + lo) * WROW + (cc + hi) * RS;
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+      for (int r = 0; r < RH; ++r)
 #pragma unroll
-        for (int s2 = 0; s2 < R; ++s2) {
+        for (int s2 = 0; s2 < RW; ++s2) {
           const float b = pbase[r * IW_t + s2];
 #pragma unroll
           for (int t = 0; t < KT; ++t) {
-            const float a = wbase[t * 32 * WROW + r * R + s2];
+            const float a = wbase[t * 32 * WROW + r * RW + s2];
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
           }
         }
@@ -221,18 +224,19 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
   }
 
   // ---- epilogue: D[row = channel][col = pixel]; row = (v&3) + 8*(v>>2) + 4*hi
-  const int n_out = n0 + ni_l, p_out = p0 + p_l;
-  if (n_out < N) {
+  const int n_out = n0 + ni_l;
+  const int h_out = (p0 + p_l) * g.os + g.ph, w_out = q_l * g.os + g.pw;
+  if (n_out < g.N) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       const int kbase = k0 + (wk * KT + t) * 32;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
-        if (k < yC) {
+        if (k < g.yC) {
           float o = acc[t][v];
-          if (bias) o += bias[k];
-          y[(((size_t)n_out * yC + k) * P + p_out) * Q + q_l] = o;
+          if (g.bias) o += g.bias[k];
+          g.y[(((size_t)n_out * g.yC + k) * g.yH + h_out) * g.yW + w_out] = o;
         }
       }
     }
@@ -436,42 +440,108 @@ inline TileGeom make_geom(int N, int P, int Q, int pixt, int cs, int R) {
   return g;
 }
 
-template <int R, int STRIDE, bool DGRAD>
-int launch_igemm(const float *x, const float *w, const float *bias, float *y, int N, int xC, int xH, int xW, int yC,
-                 int yH, int yW, int pad, int wC, int wK, hipStream_t st) {
+// rectangular-tap variant of make_geom (RH rows x RW cols of taps)
+inline TileGeom make_geom_rect(int N, int P, int Q, int pixt, int cs, int RH, int RW) {
+  TileGeom g = make_geom(N, P, Q, pixt, cs, RH);
+  if (!g.ok && g.NI == 0) return g;
+  g.IW_t = (Q - 1) * cs + RW;
+  g.ok = (g.NI > 0) && (g.NI * g.IH_t * g.IW_t) <= 3 * 256;
+  return g;
+}
+
+template <int RH, int RW, int STRIDE, bool DGRAD>
+int launch_igemm(IgemmArgs a, hipStream_t st) {
   // tile shape: prefer 128 pixels x up to 128 channels; shrink when that leaves the chip under-filled
   const int cs = DGRAD ? 1 : STRIDE;
   int pixt = 128;
-  TileGeom g = make_geom(N, yH, yW, pixt, cs, R);
-  const int kblocks128 = (yC + 127) / 128;
+  TileGeom g = make_geom_rect(a.N, a.subH, a.subW, pixt, cs, RH, RW);
+  const int kblocks128 = (a.yC + 127) / 128;
   if (!g.ok || g.ntiles * kblocks128 < 384) {
-    TileGeom g64 = make_geom(N, yH, yW, 64, cs, R);
+    TileGeom g64 = make_geom_rect(a.N, a.subH, a.subW, 64, cs, RH, RW);
     if (g64.ok) { g = g64; pixt = 64; }
   }
   if (!g.ok) return SALUN_EINVAL;
+  a.NI = g.NI; a.TP = g.TP; a.IH_t = g.IH_t; a.IW_t = g.IW_t; a.logQ = g.logQ;
   const int PSZ = g.NI * g.IH_t * g.IW_t;
   const int ch_stride = PSZ | 1;
-  constexpr int RS = R * R;
-#define SALUN_IGEMM(KT_, WP_, WK_)                                                                              \
-  {                                                                                                             \
-    constexpr int KB = WK_ * KT_ * 32;                                                                          \
-    const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));                  \
-    dim3 grid(g.ntiles, (yC + KB - 1) / KB);                                                                    \
-    allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD>, ldsb);                                               \
-    hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD>), grid, dim3(256), ldsb, st, x, w, bias, y, \
-                       N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK);             \
+  constexpr int RS = RH * RW;
+#define SALUN_IGEMM(KT_, WP_, WK_)                                                                     \
+  {                                                                                                    \
+    constexpr int KB = WK_ * KT_ * 32;                                                                 \
+    const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));         \
+    dim3 grid(g.ntiles, (a.yC + KB - 1) / KB);                                                         \
+    allow_lds(conv_igemm<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD>, ldsb);                                 \
+    hipLaunchKernelGGL((conv_igemm<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD>), grid, dim3(256), ldsb, st, a); \
   }
   if (pixt == 128) {
-    if (yC > 64) SALUN_IGEMM(4, 4, 1)
-    else if (yC > 32) SALUN_IGEMM(2, 4, 1)
+    if (a.yC > 64) SALUN_IGEMM(4, 4, 1)
+    else if (a.yC > 32) SALUN_IGEMM(2, 4, 1)
     else SALUN_IGEMM(1, 4, 1)
   } else {
     // small pixel space (deep layers): 64 x 128 tiles only if that still yields enough workgroups
-    if (yC > 64 && g.ntiles * kblocks128 >= 384) SALUN_IGEMM(2, 2, 2)
+    if (a.yC > 64 && g.ntiles * kblocks128 >= 384) SALUN_IGEMM(2, 2, 2)
     else SALUN_IGEMM(1, 2, 2)
   }
 #undef SALUN_IGEMM
   SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+inline IgemmArgs fwd_args(const float *x, const float *w, const float *bias, float *y, int N, int C, int H, int W,
+                          int K, int R, int pad, int P, int Q) {
+  IgemmArgs a{};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.N = N; a.xC = C; a.xH = H; a.xW = W; a.yC = K; a.yH = P; a.yW = Q;
+  a.subH = P; a.subW = Q; a.os = 1; a.ph = 0; a.pw = 0;
+  a.vpad_h = pad; a.vpad_w = pad;
+  a.wC = C; a.wK = K; a.Rfull = R;
+  a.rtop_h = a.rtop_w = R - 1; a.ts = 1;
+  return a;
+}
+
+// backward-data: one launch for stride 1, one launch per output parity class for stride 2
+template <int R>
+int launch_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H, int W, int K, int stride, int pad,
+                 int P, int Q, hipStream_t st) {
+  IgemmArgs a{};
+  a.x = dy; a.w = w; a.bias = nullptr; a.y = dx;
+  a.N = N; a.xC = K; a.xH = P; a.xW = Q; a.yC = C; a.yH = H; a.yW = W;
+  a.wC = C; a.wK = K; a.Rfull = R;
+  if (stride == 1) {
+    a.subH = H; a.subW = W; a.os = 1; a.ph = a.pw = 0;
+    a.rtop_h = a.rtop_w = R - 1; a.ts = 1;
+    a.vpad_h = a.vpad_w = R - 1 - pad;
+    return launch_igemm<R, R, 1, true>(a, st);
+  }
+  if ((H & 1) || (W & 1)) return SALUN_EINVAL;
+  a.subH = H / 2; a.subW = W / 2; a.os = 2; a.ts = 2;
+  // taps of parity class p: r = (p + pad) mod 2, +2, ... < R ; rtop = the largest
+  int ntap[2], rtop[2];
+  for (int p = 0; p < 2; ++p) {
+    const int r0 = (p + pad) & 1;
+    ntap[p] = (r0 < R) ? (R - 1 - r0) / 2 + 1 : 0;
+    rtop[p] = r0 + 2 * (ntap[p] - 1);
+  }
+  bool any_empty = false;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw)
+      if (ntap[ph] == 0 || ntap[pw] == 0) any_empty = true;
+  if (any_empty && hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * C * H * W, st) != hipSuccess) return SALUN_EIO;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      if (ntap[ph] == 0 || ntap[pw] == 0) continue;
+      a.ph = ph; a.pw = pw;
+      a.rtop_h = rtop[ph]; a.rtop_w = rtop[pw];
+      a.vpad_h = -((ph + pad - rtop[ph]) / 2);  // (ph + pad - rtop) is even and <= 0
+      a.vpad_w = -((pw + pad - rtop[pw]) / 2);
+      int rc;
+      if (ntap[ph] == 1 && ntap[pw] == 1) rc = launch_igemm<1, 1, 1, true>(a, st);
+      else if (ntap[ph] == 1 && ntap[pw] == 2) rc = launch_igemm<1, 2, 1, true>(a, st);
+      else if (ntap[ph] == 2 && ntap[pw] == 1) rc = launch_igemm<2, 1, 1, true>(a, st);
+      else if (ntap[ph] == 2 && ntap[pw] == 2) rc = launch_igemm<2, 2, 1, true>(a, st);
+      else return SALUN_EINVAL;
+      if (rc != SALUN_OK) return rc;
+    }
   return SALUN_OK;
 }
 
@@ -494,10 +564,11 @@ SALUN_EXPORT int salun_conv2d_forward(const float *x, const float *w, const floa
                                       salun_stream_t stream) {
   if (!x || !w || !y || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
-  if (R == 3 && stride == 1) return launch_igemm<3, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
-  if (R == 3 && stride == 2) return launch_igemm<3, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
-  if (R == 1 && stride == 1) return launch_igemm<1, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
-  if (R == 1 && stride == 2) return launch_igemm<1, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
+  const IgemmArgs a = fwd_args(x, w, bias, y, N, C, H, W, K, R, pad, P, Q);
+  if (R == 3 && stride == 1) return launch_igemm<3, 3, 1, false>(a, st);
+  if (R == 3 && stride == 2) return launch_igemm<3, 3, 2, false>(a, st);
+  if (R == 1 && stride == 1) return launch_igemm<1, 1, 1, false>(a, st);
+  if (R == 1 && stride == 2) return launch_igemm<1, 1, 2, false>(a, st);
   return SALUN_EINVAL;
 }
 
@@ -506,12 +577,10 @@ SALUN_EXPORT int salun_conv2d_backward_data(const float *dy, const float *w, flo
                                             int K, int R, int stride, int pad, int P, int Q,
                                             salun_stream_t stream) {
   if (!dy || !w || !dx || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
+  if (stride != 1 && stride != 2) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
-  // patch source = dy (K channels, P x Q), output = dx (C channels, H x W)
-  if (R == 3 && stride == 1) return launch_igemm<3, 1, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
-  if (R == 3 && stride == 2) return launch_igemm<3, 2, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
-  if (R == 1 && stride == 1) return launch_igemm<1, 1, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
-  if (R == 1 && stride == 2) return launch_igemm<1, 2, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
+  if (R == 3) return launch_dgrad<3>(dy, w, dx, N, C, H, W, K, stride, pad, P, Q, st);
+  if (R == 1) return launch_dgrad<1>(dy, w, dx, N, C, H, W, K, stride, pad, P, Q, st);
   return SALUN_EINVAL;
 }
 

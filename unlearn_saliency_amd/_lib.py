@@ -12,7 +12,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsalun.so")
+LIB_PATH = os.environ.get("SALUN_LIB") or os.path.join(_HERE, "libsalun.so")  # SALUN_LIB: A/B builds when tuning
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 SALUN_OK = 0

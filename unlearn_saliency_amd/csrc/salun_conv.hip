@@ -50,7 +50,192 @@ struct PatchPos {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// forward / backward-data
+// forward / backward-data, stride-1 walk (the fast path: forward of any stride, backward-data of stride 1)
+//   R        filter size (1 or 3), square
+//   STRIDE   forward: convolution stride; DGRAD: upsampling factor of dY (conv stride is 1)
+//   KT       32-channel output tiles per wave
+//   WP x WK  wave grid inside the workgroup: WP pixel tiles x WK channel groups (WP*WK == 4)
+//   DGRAD    backward-data mode
+// `x` is the tensor the patch is read from (forward: input; DGRAD: dY), `y` the tensor written.
+// `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
+// STRIDE and the padding is R-1-pad.
+template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
+                                                  const float *__restrict__ bias, float *__restrict__ y, int N,
+                                                  int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
+                                                  int TP, int IH_t, int IW_t, int logQ, int wC /*w dim1 (C of OIHW)*/,
+                                                  int wK /*w dim0*/) {
+  constexpr int RS = R * R;
+  constexpr int PIXT = WP * 32;        // pixels per workgroup tile
+  constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
+  constexpr int WROW = CC * RS + 1;    // LDS weight row (odd => conflict-free across 32 rows)
+  constexpr int CONV_S = DGRAD ? 1 : STRIDE;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int PSZ = NI * IH_t * IW_t;
+  const int ch_stride = PSZ | 1;
+  float *patch = lds;                   // [CC][ch_stride]
+  float *wl = lds + CC * ch_stride;     // [KB][WROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wp = wave % WP, wk = wave / WP;
+  const int Q = yW, P = yH;
+  const int tiles_per_img = (P * Q) / (TP * Q);  // row bands per image (1 when NI >= 1 image)
+  const int tile = blockIdx.x;
+  const int k0 = blockIdx.y * KB;
+  // tile -> first image / first output row
+  int n0, p0;
+  if (NI > 1) { n0 = tile * NI; p0 = 0; }
+  else { n0 = tile / tiles_per_img; p0 = (tile - n0 * tiles_per_img) * TP; }
+
+  // ---- this lane's output pixel inside the tile (fixed for the whole kernel)
+  const int mloc = wp * 32 + lo;               // 0..PIXT-1
+  const int q_l = mloc & (Q - 1);
+  const int pr = mloc >> logQ;                 // row index inside the tile (over NI*TP rows)
+  const int ni_l = pr / TP, p_l = pr - ni_l * TP;
+  const int pix_off = (ni_l * IH_t + p_l * CONV_S) * IW_t + q_l * CONV_S;  // tap (0,0) position in the patch
+
+  // ---- the (<= 3) patch positions this thread stages for every channel of a chunk
+  constexpr int MAXPOS = 3;
+  PatchPos pos[MAXPOS];
+  const int planeHW = xH * xW;
+  // virtual (possibly upsampled) input extent
+  const int vH = DGRAD ? (xH - 1) * STRIDE + 1 : xH;
+  const int vW = DGRAD ? (xW - 1) * STRIDE + 1 : xW;
+  const int vpad = DGRAD ? (R - 1 - pad) : pad;
+#pragma unroll
+  for (int j = 0; j < MAXPOS; ++j) {
+    const int e = tid + j * 256;
+    pos[j].loff = e;
+    pos[j].valid = 0;
+    pos[j].goff = 0;
+    if (e < PSZ) {
+      const int ni = e / (IH_t * IW_t);
+      const int rem = e - ni * (IH_t * IW_t);
+      const int ih = rem / IW_t, iw = rem - ih * IW_t;
+      const int n = n0 + ni;
+      const int vh = p0 * CONV_S - vpad + ih, vw = -vpad + iw;
+      bool ok = (n < N) && vh >= 0 && vh < vH && vw >= 0 && vw < vW;
+      int sh = vh, sw = vw;
+      if (DGRAD && STRIDE > 1) {
+        ok = ok && (vh % STRIDE == 0) && (vw % STRIDE == 0);
+        sh = vh / STRIDE;
+        sw = vw / STRIDE;
+      }
+      pos[j].valid = ok;
+      pos[j].goff = ok ? (n * xC * planeHW + sh * xW + sw) : 0;
+    }
+  }
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  const int Cred = xC;  // reduction channels = channels of the tensor the patch is read from
+  // Register-staged software pipeline: the global loads of chunk i+1 are issued before the MFMA section of
+  // chunk i and only consumed (written to LDS) after it, so their latency hides under the matrix work.
+  constexpr int WN = KB * CC * RS / 256;  // weight-slab elements per thread per chunk (KB*RS/32)
+  float preg[MAXPOS][CC];
+  float wreg[WN];
+
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < MAXPOS; ++j) {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        float v = 0.f;
+        if (pos[j].valid && (c0 + c) < Cred) v = x[pos[j].goff + (c0 + c) * planeHW];
+        preg[j][c] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int e = tid + i * 256;
+      float v = 0.f;
+      if (!DGRAD) {
+        // forward: rows = output channel k; global w[k][c0..c0+CC][rs] is one contiguous run per k
+        const int kk = e / (CC * RS), j = e - kk * (CC * RS);
+        const int c = j / RS;
+        if ((k0 + kk) < wK && (c0 + c) < wC) v = w[(size_t)(k0 + kk) * wC * RS + (size_t)c0 * RS + j];
+      } else {
+        // backward-data: rows = forward input channel (output of this pass), reduction over forward k;
+        // global w[k][c][rs] is contiguous over (c, rs) for a fixed k
+        const int kk = e / (KB * RS), rem = e - kk * (KB * RS);
+        const int cl = rem / RS, rs = rem - cl * RS;
+        if ((c0 + kk) < wK && (k0 + cl) < wC) v = w[(size_t)(c0 + kk) * wC * RS + (size_t)(k0 + cl) * RS + rs];
+      }
+      wreg[i] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int j = 0; j < MAXPOS; ++j)
+      if (pos[j].loff < PSZ) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) patch[c * ch_stride + pos[j].loff] = preg[j][c];
+      }
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int e = tid + i * 256;
+      if (!DGRAD) {
+        const int kk = e / (CC * RS), j = e - kk * (CC * RS);
+        wl[kk * WROW + j] = wreg[i];
+      } else {
+        const int kk = e / (KB * RS), rem = e - kk * (KB * RS);
+        const int cl = rem / RS, rs = rem - cl * RS;
+        wl[cl * WROW + kk * RS + (RS - 1 - rs)] = wreg[i];  // taps flipped while staging
+      }
+    }
+  };
+
+  load_chunk(0);
+  for (int c0 = 0; c0 < Cred; c0 += CC) {
+    __syncthreads();  // previous chunk fully consumed
+    store_chunk();
+    __syncthreads();
+    if (c0 + CC < Cred) load_chunk(c0 + CC);  // in flight during the MFMA section below
+    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1)
+#pragma unroll
+    for (int cc = 0; cc < CC; cc += 2) {
+      const float *pbase = patch + (cc + hi) * ch_stride + pix_off;
+      const float *wbase = wl + (wk * KT * 32 + lo) * WROW + (cc + hi) * RS;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+          const float b = pbase[r * IW_t + s];
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            const float a = wbase[t * 32 * WROW + r * R + s];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- epilogue: D[row = channel][col = pixel]; row = (v&3) + 8*(v>>2) + 4*hi
+  const int n_out = n0 + ni_l, p_out = p0 + p_l;
+  if (n_out < N) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int kbase = k0 + (wk * KT + t) * 32;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
+        if (k < yC) {
+          float o = acc[t][v];
+          if (bias) o += bias[k];
+          y[(((size_t)n_out * yC + k) * P + p_out) * Q + q_l] = o;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tap-mapped variant (used for the parity classes of stride-2 backward-data)
 //   RH x RW  taps staged per channel (forward: the full R x R filter; backward-data with stride 2: the 1..2 x 1..2
 //            taps that reach one output parity class)
 //   STRIDE   forward convolution stride (backward-data always walks its source with stride 1)
@@ -75,7 +260,7 @@ struct IgemmArgs {
 };
 
 template <int RH, int RW, int STRIDE, int KT, int WP, int WK, bool DGRAD>
-__global__ __launch_bounds__(256) void conv_igemm(const IgemmArgs g) {
+__global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
   constexpr int RS = RH * RW;
   constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
   constexpr int WROW = CC * RS + 1;    // LDS weight row (odd => conflict-free across 32 rows)
@@ -440,6 +625,46 @@ inline TileGeom make_geom(int N, int P, int Q, int pixt, int cs, int R) {
   return g;
 }
 
+template <int R, int STRIDE, bool DGRAD>
+int launch_igemm(const float *x, const float *w, const float *bias, float *y, int N, int xC, int xH, int xW, int yC,
+                 int yH, int yW, int pad, int wC, int wK, hipStream_t st) {
+  // tile shape: prefer 128 pixels x up to 128 channels; shrink when that leaves the chip under-filled
+  const int cs = DGRAD ? 1 : STRIDE;
+  int pixt = 128;
+  TileGeom g = make_geom(N, yH, yW, pixt, cs, R);
+  const int kblocks128 = (yC + 127) / 128;
+  if (!g.ok || g.ntiles * kblocks128 < 384) {
+    TileGeom g64 = make_geom(N, yH, yW, 64, cs, R);
+    if (g64.ok) { g = g64; pixt = 64; }
+  }
+  if (!g.ok) return SALUN_EINVAL;
+  const int PSZ = g.NI * g.IH_t * g.IW_t;
+  const int ch_stride = PSZ | 1;
+  constexpr int RS = R * R;
+#define SALUN_IGEMM(KT_, WP_, WK_)                                                                              \
+  {                                                                                                             \
+    constexpr int KB = WK_ * KT_ * 32;                                                                          \
+    const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));                  \
+    dim3 grid(g.ntiles, (yC + KB - 1) / KB);                                                                    \
+    allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD>, ldsb);                                               \
+    hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD>), grid, dim3(256), ldsb, st, x, w, bias, y, \
+                       N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK);             \
+  }
+  if (pixt == 128) {
+    if (yC > 64) SALUN_IGEMM(4, 4, 1)
+    else if (yC > 32) SALUN_IGEMM(2, 4, 1)
+    else SALUN_IGEMM(1, 4, 1)
+  } else {
+    // small pixel space (deep layers): 64 x 128 tiles only if that still yields enough workgroups
+    if (yC > 64 && g.ntiles * kblocks128 >= 384) SALUN_IGEMM(2, 2, 2)
+    else SALUN_IGEMM(1, 2, 2)
+  }
+#undef SALUN_IGEMM
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+
 // rectangular-tap variant of make_geom (RH rows x RW cols of taps)
 inline TileGeom make_geom_rect(int N, int P, int Q, int pixt, int cs, int RH, int RW) {
   TileGeom g = make_geom(N, P, Q, pixt, cs, RH);
@@ -450,7 +675,7 @@ inline TileGeom make_geom_rect(int N, int P, int Q, int pixt, int cs, int RH, in
 }
 
 template <int RH, int RW, int STRIDE, bool DGRAD>
-int launch_igemm(IgemmArgs a, hipStream_t st) {
+int launch_igemm_tap(IgemmArgs a, hipStream_t st) {
   // tile shape: prefer 128 pixels x up to 128 channels; shrink when that leaves the chip under-filled
   const int cs = DGRAD ? 1 : STRIDE;
   int pixt = 128;
@@ -470,8 +695,8 @@ int launch_igemm(IgemmArgs a, hipStream_t st) {
     constexpr int KB = WK_ * KT_ * 32;                                                                 \
     const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));         \
     dim3 grid(g.ntiles, (a.yC + KB - 1) / KB);                                                         \
-    allow_lds(conv_igemm<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD>, ldsb);                                 \
-    hipLaunchKernelGGL((conv_igemm<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD>), grid, dim3(256), ldsb, st, a); \
+    allow_lds(conv_igemm_tap<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD>, ldsb);                                 \
+    hipLaunchKernelGGL((conv_igemm_tap<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD>), grid, dim3(256), ldsb, st, a); \
   }
   if (pixt == 128) {
     if (a.yC > 64) SALUN_IGEMM(4, 4, 1)
@@ -487,18 +712,6 @@ int launch_igemm(IgemmArgs a, hipStream_t st) {
   return SALUN_OK;
 }
 
-inline IgemmArgs fwd_args(const float *x, const float *w, const float *bias, float *y, int N, int C, int H, int W,
-                          int K, int R, int pad, int P, int Q) {
-  IgemmArgs a{};
-  a.x = x; a.w = w; a.bias = bias; a.y = y;
-  a.N = N; a.xC = C; a.xH = H; a.xW = W; a.yC = K; a.yH = P; a.yW = Q;
-  a.subH = P; a.subW = Q; a.os = 1; a.ph = 0; a.pw = 0;
-  a.vpad_h = pad; a.vpad_w = pad;
-  a.wC = C; a.wK = K; a.Rfull = R;
-  a.rtop_h = a.rtop_w = R - 1; a.ts = 1;
-  return a;
-}
-
 // backward-data: one launch for stride 1, one launch per output parity class for stride 2
 template <int R>
 int launch_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H, int W, int K, int stride, int pad,
@@ -510,8 +723,7 @@ int launch_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H
   if (stride == 1) {
     a.subH = H; a.subW = W; a.os = 1; a.ph = a.pw = 0;
     a.rtop_h = a.rtop_w = R - 1; a.ts = 1;
-    a.vpad_h = a.vpad_w = R - 1 - pad;
-    return launch_igemm<R, R, 1, true>(a, st);
+    return launch_igemm<R, 1, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
   }
   if ((H & 1) || (W & 1)) return SALUN_EINVAL;
   a.subH = H / 2; a.subW = W / 2; a.os = 2; a.ts = 2;
@@ -535,10 +747,10 @@ int launch_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H
       a.vpad_h = -((ph + pad - rtop[ph]) / 2);  // (ph + pad - rtop) is even and <= 0
       a.vpad_w = -((pw + pad - rtop[pw]) / 2);
       int rc;
-      if (ntap[ph] == 1 && ntap[pw] == 1) rc = launch_igemm<1, 1, 1, true>(a, st);
-      else if (ntap[ph] == 1 && ntap[pw] == 2) rc = launch_igemm<1, 2, 1, true>(a, st);
-      else if (ntap[ph] == 2 && ntap[pw] == 1) rc = launch_igemm<2, 1, 1, true>(a, st);
-      else if (ntap[ph] == 2 && ntap[pw] == 2) rc = launch_igemm<2, 2, 1, true>(a, st);
+      if (ntap[ph] == 1 && ntap[pw] == 1) rc = launch_igemm_tap<1, 1, 1, true>(a, st);
+      else if (ntap[ph] == 1 && ntap[pw] == 2) rc = launch_igemm_tap<1, 2, 1, true>(a, st);
+      else if (ntap[ph] == 2 && ntap[pw] == 1) rc = launch_igemm_tap<2, 1, 1, true>(a, st);
+      else if (ntap[ph] == 2 && ntap[pw] == 2) rc = launch_igemm_tap<2, 2, 1, true>(a, st);
       else return SALUN_EINVAL;
       if (rc != SALUN_OK) return rc;
     }
@@ -564,11 +776,10 @@ SALUN_EXPORT int salun_conv2d_forward(const float *x, const float *w, const floa
                                       salun_stream_t stream) {
   if (!x || !w || !y || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
-  const IgemmArgs a = fwd_args(x, w, bias, y, N, C, H, W, K, R, pad, P, Q);
-  if (R == 3 && stride == 1) return launch_igemm<3, 3, 1, false>(a, st);
-  if (R == 3 && stride == 2) return launch_igemm<3, 3, 2, false>(a, st);
-  if (R == 1 && stride == 1) return launch_igemm<1, 1, 1, false>(a, st);
-  if (R == 1 && stride == 2) return launch_igemm<1, 1, 2, false>(a, st);
+  if (R == 3 && stride == 1) return launch_igemm<3, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
+  if (R == 3 && stride == 2) return launch_igemm<3, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
+  if (R == 1 && stride == 1) return launch_igemm<1, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
+  if (R == 1 && stride == 2) return launch_igemm<1, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
   return SALUN_EINVAL;
 }
 

@@ -196,22 +196,30 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
     store_chunk();
     __syncthreads();
     if (c0 + CC < Cred) load_chunk(c0 + CC);  // in flight during the MFMA section below
-    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1)
+    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1).
+    // The (1 + KT) LDS operands of k-step i+1 are read while the KT MFMAs of k-step i run (one-step-ahead
+    // software pipeline, pinned with scheduling barriers): no MFMA waits for an LDS round trip.
+    constexpr int NSTEP = (CC / 2) * RS;
+    const float *pb0 = patch + hi * ch_stride + pix_off;
+    const float *wb0 = wl + (wk * KT * 32 + lo) * WROW + hi * RS;
+    auto operands = [&](int step, float &bv, float (&av)[KT]) {
+      const int cc = 2 * (step / RS), rs = step % RS, r = rs / R, s2 = rs % R;  // compile-time after unrolling
+      bv = pb0[cc * ch_stride + r * IW_t + s2];
 #pragma unroll
-    for (int cc = 0; cc < CC; cc += 2) {
-      const float *pbase = patch + (cc + hi) * ch_stride + pix_off;
-      const float *wbase = wl + (wk * KT * 32 + lo) * WROW + (cc + hi) * RS;
+      for (int t = 0; t < KT; ++t) av[t] = wb0[t * 32 * WROW + cc * RS + rs];
+    };
+    float b_cur, a_cur[KT], b_nxt = 0.f, a_nxt[KT];
+    operands(0, b_cur, a_cur);
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + 1 < NSTEP) operands(step + 1, b_nxt, a_nxt);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < R; ++s) {
-          const float b = pbase[r * IW_t + s];
+      for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      b_cur = b_nxt;
 #pragma unroll
-          for (int t = 0; t < KT; ++t) {
-            const float a = wbase[t * 32 * WROW + r * R + s];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-          }
-        }
+      for (int t = 0; t < KT; ++t) a_cur[t] = a_nxt[t];
     }
   }
 

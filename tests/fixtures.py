@@ -121,3 +121,10 @@ def ddpm_batch(n, seed, image_size=16, label=None):
 
 def flat_params(model):
     return np.concatenate([p.detach().reshape(-1).cpu().numpy() for p in model.parameters()])
+
+
+# -------------------------------------------------------------------- SD fixtures
+def sd_tiny_config():
+    return dict(image_size=8, in_channels=4, out_channels=4, model_channels=32, attention_resolutions=(2, 1),
+                num_res_blocks=1, channel_mult=(1, 2), num_heads=4, use_spatial_transformer=True, transformer_depth=1,
+                context_dim=24, use_checkpoint=False, legacy=False)

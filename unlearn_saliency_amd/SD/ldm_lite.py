@@ -1,0 +1,78 @@
+"""`LatentDiffusionLite`: the slice of the reference's `LatentDiffusion`
+(SD/ldm/models/diffusion/ddpm.py:424-430 q_sample, :913-973 get_input, :1093-1109 shared_step,
+:1121 apply_model, :1286-1319 p_losses) that the SalUn scripts call — schedule buffers, `q_sample`,
+`apply_model`, `shared_step`, `get_input` — around the U-Net of unet.py.
+
+The frozen first stage (AutoencoderKL) and text encoder (CLIP) are outside the hot-path scope (SURVEY.md §2 S4;
+their weights are not available offline), so batches carry *latents and context embeddings* directly:
+``{"z": (B,4,64,64) fp32, "c": (B,77,768) fp32}``.  A caller that has the encoders can pass
+`first_stage` / `cond_stage` callables and feed the reference's ``{"jpg": ..., "txt": ...}`` batches.
+Parameter names keep the reference's prefix (`model.diffusion_model.*`), which is what the mask-key
+rewrite in the scripts (`n.split("model.diffusion_model.")[-1]`, random_label.py:135) relies on.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .unet import UNetModel, V1_UNET_CONFIG
+
+
+class _Wrapper(nn.Module):
+    def __init__(self, unet):
+        super().__init__()
+        self.diffusion_model = unet
+
+
+class LatentDiffusionLite(nn.Module):
+    def __init__(self, unet_config=None, timesteps=1000, linear_start=0.00085, linear_end=0.0120,
+                 first_stage=None, cond_stage=None, scale_factor=0.18215, bf16=False):
+        super().__init__()
+        self.model = _Wrapper(UNetModel(**(unet_config or V1_UNET_CONFIG)))
+        self.num_timesteps = int(timesteps)
+        self.first_stage_key, self.cond_stage_key = "jpg", "txt"
+        self.first_stage, self.cond_stage, self.scale_factor = first_stage, cond_stage, scale_factor
+        self.bf16 = bf16
+        # "linear" schedule of the LDM code base: linspace(sqrt(start), sqrt(end))**2 in float64 (util.py:24-30)
+        betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=np.float64) ** 2
+        ac = np.cumprod(1.0 - betas, axis=0)
+        self.register_buffer("sqrt_alphas_cumprod", torch.tensor(np.sqrt(ac), dtype=torch.float32))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32))
+
+    @property
+    def device(self):
+        return self.sqrt_alphas_cumprod.device
+
+    # ---- the calls the scripts make
+    def get_input(self, batch, k=None):
+        """-> (z, c).  Accepts {"z","c"} (latents + context) or, with encoders attached, {"jpg","txt"}."""
+        if "z" in batch:
+            return batch["z"].to(self.device), batch["c"].to(self.device)
+        if self.first_stage is None or self.cond_stage is None:
+            raise RuntimeError("image/text batches need the frozen VAE and CLIP encoders (out of the hot-path scope); "
+                               "feed {'z': latents, 'c': context} batches or attach first_stage/cond_stage callables")
+        x = batch["jpg"].permute(0, 3, 1, 2).to(self.device).float()
+        with torch.no_grad():
+            return self.first_stage(x) * self.scale_factor, self.cond_stage(batch["txt"])
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        return ops.qsample(x_start.contiguous().float(), noise.contiguous().float(), self.sqrt_alphas_cumprod,
+                           self.sqrt_one_minus_alphas_cumprod, t.to(torch.int64).contiguous())
+
+    def apply_model(self, x_noisy, t, cond):
+        if self.bf16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return self.model.diffusion_model(x_noisy, t, context=cond).float()
+        return self.model.diffusion_model(x_noisy, t, context=cond)
+
+    def shared_step(self, batch):
+        """(loss, {}) with loss = mean MSE(noise, eps(x_t, t, c)) — the reference's p_losses with
+        logvar = 0, l_simple_weight = 1, original_elbo_weight = 0 (ddpm.py:82-90,1286-1319)."""
+        x, c = self.get_input(batch, self.first_stage_key)
+        t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=self.device).long()
+        noise = torch.randn_like(x)
+        out = self.apply_model(self.q_sample(x, t, noise), t, c)
+        return ops.mse_loss(noise, out), {}

@@ -233,6 +233,17 @@ def main():
     # per-step device time from consecutive event timestamps (shows clock/thermal drift over the run)
     step_ms = [events[i][0].elapsed_time(events[i + 1][0]) for i in range(len(events) - 1)]
 
+    # forward+backward device time per step: from the end of the previous step's update to the start of this one's
+    fb_ms = [events[i][1].elapsed_time(events[i + 1][0]) for i in range(len(events) - 1)]
+    fb_mean_s = 1e-3 * sum(fb_ms) / max(len(fb_ms), 1)
+    pmc_traffic, pmc_src = None, None
+    try:  # HBM bytes per launch from the committed PMC passes (tools/pmc.sh; never collected inside this run)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc_traffic = json.load(f)["kernels"]["k_masked_sgd_vec@n18"]["traffic_bytes"]
+            pmc_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    except Exception:
+        pass
+
     if rank == 0:
         steps_per_s = a.steps * world / dt
         alg_bytes = SGD_BYTES_PER_ELEM * N18
@@ -255,13 +266,18 @@ def main():
                               "max": round(max(step_ms), 2) if step_ms else None},
             "roofline": {"kernel": "salun_masked_sgd_step" + ("" if world == 1 else " (+ flat-gradient all-reduce)"),
                          "bound": "hbm", "achieved": alg_bytes / tail_mean_s / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": alg_bytes / tail_mean_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": alg_bytes / tail_mean_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic,
+                         "traffic_source": pmc_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": tail_mean_s * 1e6,
                          "median_launch_us": 1e3 * tail_ms[len(tail_ms) // 2],
                          "timing": "HIP events on the launch stream around the launch, inside the timed steps"},
             "fwd_bwd": {"bound": "mfma", "gflop_per_step": FWD_BWD_GFLOP_PER_IMG * a.batch_size,
-                        "achieved_tflops_whole_step": FWD_BWD_GFLOP_PER_IMG * a.batch_size / (1e3 * dt / a.steps) ,
-                        "peak_tflops_fp32": FP32_MATRIX_PEAK_TF,
+                        "achieved": FWD_BWD_GFLOP_PER_IMG * a.batch_size / (fb_mean_s * 1e3) if fb_mean_s else None,
+                        "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": (FWD_BWD_GFLOP_PER_IMG * a.batch_size / (fb_mean_s * 1e3) / FP32_MATRIX_PEAK_TF)
+                        if fb_mean_s else None,
+                        "mean_fwd_bwd_ms": fb_mean_s * 1e3,
+                        "timing": "HIP events: end of step i's update -> start of step i+1's update",
                         "note": ("convolutions: hand-written fp32 MFMA implicit-GEMM kernels (salun_conv2d_*); "
                                  "BN/ReLU/pool/fc: PyTorch-ROCm") if n_salun_convs else
                                 "convolutions/GEMMs run in MIOpen/rocBLAS fp32 through PyTorch-ROCm"},

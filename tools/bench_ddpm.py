@@ -1,0 +1,88 @@
+"""DDPM class-forget benchmark (BASELINE.json configs[3]): CFG-DDPM U-Net (38,632,323 params), CIFAR-shaped
+synthetic data, class 0 forget, batch 128 — times Phase A (40 forget batches, CFG loss, per-batch clip) and the
+masked unlearning step (method rl: remain pass + forget pass + pseudo pass, clip -> mask -> fused Adam).
+Prints one JSON line.  python tools/bench_ddpm.py [--steps K] [--warmup W] [--mask_batches M] [--library_conv]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import contextlib
+import torch
+from types import SimpleNamespace
+
+ND = 38_632_323
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mask_batches", type=int, default=40)
+    ap.add_argument("--library_conv", action="store_true")
+    a = ap.parse_args()
+    from unlearn_saliency_amd.DDPM.functions import load_config, get_optimizer, cycle
+    from unlearn_saliency_amd.DDPM.runners.diffusion import Diffusion
+    from unlearn_saliency_amd.flat import arena_of
+    from unlearn_saliency_amd import ops
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = load_config(os.path.join(here, "..", "unlearn_saliency_amd", "DDPM", "configs", "cifar10_saliency_unlearn.yml"))
+    args = SimpleNamespace(ckpt_folder=None, label_to_forget=0, cond_scale=2.0, mask_path=None, method="rl",
+                           alpha=1e-3, synthetic=True, library_conv=a.library_conv)
+    torch.manual_seed(1234)
+    torch.backends.cudnn.benchmark = True
+    with contextlib.redirect_stdout(sys.stderr):
+        runner = Diffusion(args, cfg)
+        remain_loader, forget_loader = runner._loaders()
+        model = runner._load_model()
+    arena = arena_of(model)
+    assert arena.n == ND
+    # Phase A
+    fb = []
+    it = iter(cycle(forget_loader))
+    for _ in range(a.mask_batches):
+        fb.append(next(it))
+    runner.accumulate_saliency(model, fb[:2], arena)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = runner.accumulate_saliency(model, fb, arena)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    mask = ops.mask_topk(acc, [int(ND * 0.5)])[0]
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    # Phase B
+    opt = get_optimizer(cfg, arena=arena)
+    opt.set_mask(mask)
+    model.train()
+    ri, fi = cycle(remain_loader), cycle(forget_loader)
+    for _ in range(a.warmup):
+        runner.unlearn_step(model, opt, next(ri), next(fi))
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t3 = time.perf_counter()
+    for i in range(a.steps):
+        # events bracket the optimizer tail by patching step(): record before/after
+        real_step = opt.step
+        def timed_step(real=real_step, e=ev[i]):
+            e[0].record(); r = real(); e[1].record(); return r
+        opt.step = timed_step
+        runner.unlearn_step(model, opt, next(ri), next(fi))
+        opt.step = real_step
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t3
+    tail_s = 1e-3 * sum(s.elapsed_time(e) for s, e in ev) / a.steps
+    alg = 33 * ND  # grad sq-norm (4 B) + masked Adam (29 B) per element, SURVEY.md §8 D2
+    flops_step = 128 * (2 * 37.34 + 12.45) * 1e9
+    out = {"metric": "ddpm_unlearn_steps_per_sec (CFG-DDPM/CIFAR-10 class-forget, rl, batch 128)",
+           "value": a.steps / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt / a.steps, "steps": a.steps,
+           "dtype": "f32", "data": "synthetic", "params": ND,
+           "mask_gen": {"batches": a.mask_batches, "saliency_sec": t1 - t0, "topk_sec": t2 - t1},
+           "roofline": {"kernel": "salun_grad_sqnorm + salun_masked_adam_step", "bound": "hbm",
+                        "achieved": alg / tail_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / tail_s / 1e9 / 8000.0,
+                        "mean_tail_us": tail_s * 1e6, "algorithmic_bytes": alg},
+           "fwd_bwd": {"bound": "mfma", "tflop_per_step": flops_step / 1e12,
+                       "achieved_whole_step": flops_step / (dt / a.steps) / 1e12, "peak": 157.3, "unit": "TFLOP/s"},
+           "mfma_convs": not a.library_conv}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

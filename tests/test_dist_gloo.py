@@ -168,3 +168,41 @@ def test_sharded_step_equals_single_process_and_ranks_agree(tmp_path):
     buf = np.zeros_like(flat)
     oracle.masked_sgd_step(flat, g, buf, (np.arange(flat.size) % 2).astype(np.uint8), 0.013, 0.9, 5e-4, True)
     assert np.allclose(p0, flat, rtol=1e-6, atol=1e-8)
+
+
+# -------------------------------------------------- bucketed, overlapped gradient all-reduce
+def _bucketed(rank, out_dir):
+    from fixtures import TinyCNN, tiny_batches, tiny_state
+    from unlearn_saliency_amd import dist as sdist
+    from unlearn_saliency_amd.flat import FlatArena
+    model = TinyCNN()
+    model.load_state_dict(tiny_state(21))
+    model.eval()
+    arena = FlatArena.from_module(model, device="cpu")
+    red = sdist.BucketedGradReducer(arena, num_buckets=3)
+    assert red.bounds[0][0] == 0 and red.bounds[-1][1] == arena.n and len(red.bounds) >= 2
+    assert all(a[1] == b[0] for a, b in zip(red.bounds, red.bounds[1:]))
+    x, y = tiny_batches(1, 16, 700)[0]
+    lo, hi = sdist.shard_bounds(16)
+    for _ in range(2):  # two steps: state resets between them
+        arena.zero_grad()
+        nn.CrossEntropyLoss()(model(torch.from_numpy(x[lo:hi])), torch.from_numpy(y[lo:hi])).backward()
+        assert any(red.launched)  # slices went out during backward
+        red.finish()
+        assert not any(red.launched) and not red.works
+    np.save(os.path.join(out_dir, f"g_{rank}.npy"), arena.grads.numpy())
+
+
+def test_bucketed_overlapped_allreduce_equals_full_batch_gradient(tmp_path):
+    _run("_bucketed", tmp_path)
+    g0, g1 = np.load(tmp_path / "g_0.npy"), np.load(tmp_path / "g_1.npy")
+    assert np.array_equal(g0, g1)
+    sys.path.insert(0, ROOT)
+    from fixtures import TinyCNN, tiny_batches, tiny_state
+    model = TinyCNN()
+    model.load_state_dict(tiny_state(21))
+    model.eval()
+    x, y = tiny_batches(1, 16, 700)[0]
+    nn.CrossEntropyLoss()(model(torch.from_numpy(x)), torch.from_numpy(y)).backward()
+    g = np.concatenate([p.grad.reshape(-1).numpy() for p in model.parameters()])
+    assert np.allclose(g0, g, rtol=1e-5, atol=1e-7)

@@ -81,3 +81,80 @@ def shard_bounds(n: int, rk: Optional[int] = None, ws: Optional[int] = None) -> 
     ws = world_size() if ws is None else ws
     per = (n + ws - 1) // ws
     return min(rk * per, n), min((rk + 1) * per, n)
+
+
+class BucketedGradReducer:
+    """Overlap the per-step gradient all-reduce with backward.
+
+    The flat gradient is cut into `num_buckets` contiguous slices (equal element counts, snapped to parameter
+    boundaries).  Backward fills the flat vector from its END (last layers first); a post-accumulate hook per
+    parameter counts arrivals and, as soon as a slice is complete, issues `all_reduce(AVG)` on that slice with
+    `async_op=True` — RCCL runs it on its own stream after the compute stream's work queued so far, while autograd
+    keeps producing earlier layers' gradients.  `finish()` (called by the fused optimizer before its kernel)
+    reduces whatever did not fire (unused parameters) and makes the compute stream wait for all slices.
+    Few large messages (N/num_buckets x 4 B each: 11 MB for ResNet-18 with 4 buckets) are what the point-to-point
+    xGMI links want; no per-tensor buckets, no parameter broadcast (replicas stay bit-identical)."""
+
+    def __init__(self, arena, num_buckets: int = 4):
+        self.arena = arena
+        n = arena.n
+        target = [n * (i + 1) // num_buckets for i in range(num_buckets)]
+        ends, j = [], 0
+        for off, k in zip(arena.offsets, arena.numels):
+            if off + k >= target[j]:
+                ends.append(off + k)
+                while j < num_buckets - 1 and off + k >= target[j]:
+                    j += 1
+                if off + k >= n:
+                    break
+        if not ends or ends[-1] != n:
+            ends.append(n)
+        ends = sorted(set(ends))
+        self.bounds = list(zip([0] + ends[:-1], ends))
+        self.bucket_of = []
+        b = 0
+        for off in arena.offsets:
+            while off >= self.bounds[b][1]:
+                b += 1
+            self.bucket_of.append(b)
+        self.expected = [self.bucket_of.count(i) for i in range(len(self.bounds))]
+        self.arrived = [0] * len(self.bounds)
+        self.launched = [False] * len(self.bounds)
+        self.works = []
+        self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
+                         for i, p in enumerate(arena._params)]
+
+    def _make_hook(self, pidx):
+        b = self.bucket_of[pidx]
+
+        def hook(_param):
+            self.arrived[b] += 1
+            if self.arrived[b] == self.expected[b] and not self.launched[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi = self.bounds[b]
+        sl = self.arena.grads[lo:hi]
+        self.launched[b] = True
+        if dist.get_backend() == "nccl":
+            self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.AVG, async_op=True), None))
+        else:
+            self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True), sl))
+
+    def finish(self):
+        for b in range(len(self.bounds)):
+            if not self.launched[b]:
+                self._launch(b)
+        ws = world_size()
+        for work, needs_div in self.works:
+            work.wait()
+            if needs_div is not None:
+                needs_div.div_(ws)
+        self.works.clear()
+        self.arrived = [0] * len(self.bounds)
+        self.launched = [False] * len(self.bounds)
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()

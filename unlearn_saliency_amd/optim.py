@@ -21,6 +21,11 @@ class _FlatOptimizer(torch.optim.Optimizer):
         super().__init__(arena._params, defaults)
         self.mask_u8: Optional[torch.Tensor] = None
         self.steps = 0
+        self.overlap_buckets = 4
+        self._reducer = None
+        if world_size() > 1:
+            from .dist import BucketedGradReducer
+            self._reducer = BucketedGradReducer(arena, self.overlap_buckets)
 
     def set_mask(self, mask_u8: Optional[torch.Tensor]) -> None:
         """Flat u8 0/1 vector (FlatArena.pack_mask) or None for an unmasked update."""
@@ -32,7 +37,17 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.arena.zero_grad()
 
     def _sync_grads(self) -> None:
-        if world_size() > 1:  # data parallel: ONE collective over the flat gradient (RCCL over xGMI)
+        """Data parallel: mean of the flat gradient over ranks.  By default the all-reduce is cut into a few large
+        slices that start during backward (dist.BucketedGradReducer); `overlap_buckets = 0` falls back to one
+        collective over the whole vector after backward."""
+        if world_size() <= 1:
+            return
+        if self.overlap_buckets > 0:
+            if self._reducer is None:  # first step: hooks were not installed before this backward ran
+                from .dist import BucketedGradReducer
+                self._reducer = BucketedGradReducer(self.arena, self.overlap_buckets)
+            self._reducer.finish()
+        else:
             all_reduce_mean_(self.arena.grads)
 
 

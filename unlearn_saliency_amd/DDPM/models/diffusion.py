@@ -72,8 +72,8 @@ class Downsample(nn.Module):
     def forward(self, x):
         if not self.with_conv:
             return F.avg_pool2d(x, 2, 2)
-        if (self.use_mfma and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-                and not torch.is_autocast_enabled()):
+        if self.use_mfma and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+            x = x.contiguous()
             # the (0,1,0,1) zero padding is folded into the kernel: low-side pad 0, output size fixes the rest
             from ...conv import conv2d_lowpad
             return conv2d_lowpad(x, self.conv.weight, self.conv.bias, 2, 0, x.shape[2] // 2, x.shape[3] // 2)
@@ -127,7 +127,7 @@ class AttnBlock(nn.Module):
         h = self.norm(x)
         tok = lambda t: t.reshape(b, 1, c, hh * ww).transpose(2, 3)  # (b, 1, hw, c)
         o = F.scaled_dot_product_attention(tok(self.q(h)), tok(self.k(h)), tok(self.v(h)), scale=float(c) ** -0.5)
-        o = o.transpose(2, 3).reshape(b, c, hh, ww)
+        o = o.transpose(2, 3).reshape(b, c, hh, ww).contiguous()  # back to NCHW (the reshape alone is a channels-last view)
         return x + self.proj_out(o)
 
 

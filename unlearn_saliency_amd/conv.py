@@ -58,8 +58,10 @@ class SalunConv2d(nn.Conv2d):
     """Same parameters / state_dict as nn.Conv2d; fp32 NCHW device tensors go through the MFMA kernels."""
 
     def forward(self, x):
-        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
-                and not torch.is_autocast_enabled()):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled():
+            # NCHW-contiguous is the kernels' layout; a strided view (e.g. the channels-last result of an attention
+            # reshape) is materialised once here rather than sending the whole rest of the network down the library path
+            x = x.contiguous()
             R, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
             P = (x.shape[2] + 2 * p - R) // s + 1
             Q = (x.shape[3] + 2 * p - R) // s + 1

@@ -59,7 +59,7 @@ struct PatchPos {
 // `x` is the tensor the patch is read from (forward: input; DGRAD: dY), `y` the tensor written.
 // `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
 // STRIDE and the padding is R-1-pad.
-template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD>
+template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
                                                   const float *__restrict__ bias, float *__restrict__ y, int N,
                                                   int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
@@ -137,10 +137,40 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
   // Register-staged software pipeline: the global loads of chunk i+1 are issued before the MFMA section of
   // chunk i and only consumed (written to LDS) after it, so their latency hides under the matrix work.
   constexpr int WN = KB * CC * RS / 256;  // weight-slab elements per thread per chunk (KB*RS/32)
+  // FAST staging (reduction channels a multiple of CC, channel tile inside the tensor, 16-B aligned weights):
+  // the slab is fetched as float4 and no per-element bounds test remains in the hot loop.
+  constexpr int ROWF4 = DGRAD ? (KB * RS / 4) : (CC * RS / 4);  // float4 per contiguous global run
+  constexpr int NF4 = DGRAD ? (CC * ROWF4) : (KB * ROWF4);      // float4 per chunk
+  constexpr int WN4 = (NF4 + 255) / 256;
   float preg[MAXPOS][CC];
-  float wreg[WN];
+  float wreg[FAST ? 1 : WN];
+  float4 wreg4[FAST ? WN4 : 1];
 
   auto load_chunk = [&](int c0) {
+    if (FAST) {
+#pragma unroll
+      for (int j = 0; j < MAXPOS; ++j) {
+        if (pos[j].valid) {
+          const float *src = x + pos[j].goff + c0 * planeHW;
+#pragma unroll
+          for (int c = 0; c < CC; ++c) preg[j][c] = src[c * planeHW];
+        } else {
+#pragma unroll
+          for (int c = 0; c < CC; ++c) preg[j][c] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < WN4; ++i) {
+        const int e4 = tid + i * 256;
+        if (NF4 % 256 == 0 || e4 < NF4) {
+          const int row = e4 / ROWF4, q4 = e4 - row * ROWF4;
+          const float *src = DGRAD ? (w + (size_t)(c0 + row) * wC * RS + (size_t)k0 * RS + 4 * q4)
+                                   : (w + (size_t)(k0 + row) * wC * RS + (size_t)c0 * RS + 4 * q4);
+          wreg4[i] = *reinterpret_cast<const float4 *>(src);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < MAXPOS; ++j) {
 #pragma unroll
@@ -176,6 +206,27 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
 #pragma unroll
         for (int c = 0; c < CC; ++c) patch[c * ch_stride + pos[j].loff] = preg[j][c];
       }
+    if (FAST) {
+#pragma unroll
+      for (int i = 0; i < WN4; ++i) {
+        const int e4 = tid + i * 256;
+        if (NF4 % 256 == 0 || e4 < NF4) {
+          const int row = e4 / ROWF4, q4 = e4 - row * ROWF4;
+          const float v4[4] = {wreg4[i].x, wreg4[i].y, wreg4[i].z, wreg4[i].w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (!DGRAD) {
+              wl[row * WROW + 4 * q4 + u] = v4[u];
+            } else {
+              const int idx = 4 * q4 + u;              // position in the (cl, rs) run of reduction row `row`
+              const int cl = idx / RS, rs = idx - cl * RS;
+              wl[cl * WROW + row * RS + (RS - 1 - rs)] = v4[u];  // taps flipped while staging
+            }
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
       const int e = tid + i * 256;
@@ -654,9 +705,18 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
     constexpr int KB = WK_ * KT_ * 32;                                                                          \
     const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));                  \
     dim3 grid(g.ntiles, (yC + KB - 1) / KB);                                                                    \
-    allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD>, ldsb);                                               \
-    hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD>), grid, dim3(256), ldsb, st, x, w, bias, y, \
-                       N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK);             \
+    /* FAST staging: full reduction chunks, channel tile inside the tensor, float4-aligned weight runs */      \
+    const bool fast = (xC % CC == 0) && (yC % KB == 0) && salun_aligned16(w) && ((wC * RS) % 4 == 0) &&         \
+                      !(DGRAD && STRIDE > 1);                                                                   \
+    if (fast) {                                                                                                 \
+      allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>, ldsb);                                       \
+      hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>), grid, dim3(256), ldsb, st, x, w,  \
+                         bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK);  \
+    } else {                                                                                                    \
+      allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, false>, ldsb);                                      \
+      hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, false>), grid, dim3(256), ldsb, st, x, w, \
+                         bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK);  \
+    }                                                                                                           \
   }
   if (pixt == 128) {
     if (yC > 64) SALUN_IGEMM(4, 4, 1)

@@ -56,6 +56,8 @@ def parse():
                     help="1 = keep cudnn.deterministic=True as the reference's setup_seed sets it (restricts MIOpen's "
                          "algorithm choice); 0 = let MIOpen pick its fastest fp32 kernels (same math, fp32)")
     ap.add_argument("--channels_last", type=int, default=0, help="1 = NHWC activations/weights")
+    ap.add_argument("--fused_bn", type=int, default=1,
+                    help="1 = BatchNorm(+residual)+ReLU as fused kernels (csrc/salun_norm.hip); 0 = PyTorch-ROCm ops")
     ap.add_argument("--salun_conv", type=int, default=1,
                     help="1 = convolutions on the hand-written fp32 MFMA kernels (csrc/salun_conv.hip); "
                          "0 = library (MIOpen) convolutions")
@@ -169,6 +171,10 @@ def main():
     if a.salun_conv and not a.channels_last:
         from unlearn_saliency_amd.conv import use_salun_convs
         n_salun_convs = use_salun_convs(model)
+    n_fused_bn = 0
+    if a.fused_bn and not a.channels_last:
+        from unlearn_saliency_amd.norm import use_fused_bn
+        n_fused_bn = use_fused_bn(model)
     criterion = nn.CrossEntropyLoss()
     arena = arena_of(model)
     assert arena.n == N18
@@ -257,7 +263,8 @@ def main():
                                    "SGD lr 0.013 momentum 0.9 wd 5e-4, RandomCrop+flip on device",
                        "per_gpu_batch": a.batch_size, "global_batch": a.batch_size * world,
                        "parallelism": f"dp{world}", "params": N18, "cudnn_deterministic": bool(a.deterministic),
-                       "channels_last": bool(a.channels_last), "salun_mfma_convs": n_salun_convs},
+                       "channels_last": bool(a.channels_last), "salun_mfma_convs": n_salun_convs,
+                       "fused_bn_layers": n_fused_bn},
             "samples_per_sec": steps_per_s * a.batch_size,
             "mask_gen_sec": None if mask_gen is None else mask_gen["total_sec"],
             "mask_gen": mask_gen,
@@ -279,7 +286,8 @@ def main():
                         "mean_fwd_bwd_ms": fb_mean_s * 1e3,
                         "timing": "HIP events: end of step i's update -> start of step i+1's update",
                         "note": ("convolutions: hand-written fp32 MFMA implicit-GEMM kernels (salun_conv2d_*); "
-                                 "BN/ReLU/pool/fc: PyTorch-ROCm") if n_salun_convs else
+                                 + ("BN(+add)+ReLU: fused kernels (salun_bn_*); pool/fc/CE: PyTorch-ROCm" if n_fused_bn
+                                   else "BN/ReLU/pool/fc: PyTorch-ROCm")) if n_salun_convs else
                                 "convolutions/GEMMs run in MIOpen/rocBLAS fp32 through PyTorch-ROCm"},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -211,6 +211,29 @@ int salun_conv2d_backward_weight(const float *x /*dev*/, const float *dy /*dev*/
                                  int H, int W, int K, int R, int stride, int pad, int P, int Q, int accumulate,
                                  void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 
+/* Fused BatchNorm2d (+ residual add) (+ ReLU), NCHW fp32, forward and backward — replaces the
+ * bn -> relu / bn -> (+identity) -> relu chains of the classifier blocks
+ *   (Classification/models/ResNet.py:108-125,307-309) that run as separate library launches.
+ * Semantics of torch.nn.BatchNorm2d: training -> batch statistics (biased variance), running stats updated with
+ * `momentum` (unbiased variance); eval -> running statistics.  HW must be a multiple of 4, pointers 16-B aligned.
+ *   forward : y = [relu]( gamma*(x-mean)*invstd + beta [+ res] ); save_mean / save_invstd (C floats) are outputs
+ *   backward: dz = dy*[y>0] (relu) ; dbeta = sum dz ; dgamma = sum dz*xhat ;
+ *             dx = gamma*invstd*(dz - (dbeta + xhat*dgamma)/(N*HW))   (training)   |   gamma*invstd*dz   (eval)
+ *             dres = dz  (if non-NULL: gradient of the residual input)
+ * Reductions are per-(channel, batch-slice) fp64 partials folded in a fixed order: deterministic.
+ * Workspace: salun_bn_workspace_bytes(C). */
+size_t salun_bn_workspace_bytes(int C);
+int salun_bn_forward(const float *x /*dev*/, const float *res /*dev or NULL*/, float *y /*dev*/,
+                     const float *gamma /*dev*/, const float *beta /*dev*/, float *running_mean /*dev or NULL*/,
+                     float *running_var /*dev or NULL*/, float *save_mean /*dev*/, float *save_invstd /*dev*/,
+                     int N, int C, int HW, int training, double momentum, double eps, int relu, void *ws /*dev*/,
+                     size_t ws_bytes, salun_stream_t stream);
+int salun_bn_backward(const float *dy /*dev*/, const float *y /*dev, needed if relu*/, const float *x /*dev*/,
+                      const float *gamma /*dev*/, const float *save_mean /*dev*/, const float *save_invstd /*dev*/,
+                      float *dx /*dev*/, float *dres /*dev or NULL*/, float *dgamma /*dev*/, float *dbeta /*dev*/,
+                      int N, int C, int HW, int training, int relu, void *ws /*dev*/, size_t ws_bytes,
+                      salun_stream_t stream);
+
 /* ------------------------------------------------------------------ K0 --
  * Device-resident CIFAR batch assembly (replaces the host DataLoader path
  * Classification/dataset.py:542-556 + main_random.py:38-48: PIL RandomCrop(32,4)

@@ -1,0 +1,84 @@
+"""Fused BatchNorm(+add)(+ReLU) kernels vs PyTorch's fp32 reference ops (training and eval mode), and the
+ResNet-18 module switch end to end."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(256, 64, 32, 32), (32, 128, 16, 16), (16, 256, 8, 8), (64, 512, 4, 4), (3, 8, 2, 2)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_fused_bn_matches_torch(shape, training, relu, res):
+    from unlearn_saliency_amd.norm import fused_bn_act
+    torch.manual_seed(0)
+    N, C, H, W = shape
+    x = (torch.randn(shape, device="cuda") * 2 + 0.5).requires_grad_(True)
+    r = torch.randn(shape, device="cuda").requires_grad_(True) if res else None
+    bn = nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+    ref = nn.BatchNorm2d(C).cuda()
+    ref.load_state_dict(bn.state_dict())
+    bn.train(training); ref.train(training)
+    y = fused_bn_act(x, bn, residual=r, relu=relu)
+    x2 = x.detach().clone().requires_grad_(True)
+    r2 = r.detach().clone().requires_grad_(True) if res else None
+    y2 = ref(x2)
+    if res:
+        y2 = y2 + r2
+    z2 = y2
+    if relu:
+        y2 = F.relu(y2)
+    assert torch.allclose(y, y2, rtol=1e-4, atol=1e-5)
+    # pre-activations within rounding of 0 may sit on different sides of the ReLU in the two computations:
+    # give those (a handful out of millions) no upstream gradient so the comparison is well defined
+    dy = torch.randn_like(y) * (z2.detach().abs() > 1e-5)
+    y.backward(dy); y2.backward(dy)
+    tol = lambda t: 2e-5 * float(t.abs().max()) + 1e-6
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=tol(x2.grad))
+    assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=1e-4, atol=tol(ref.weight.grad))
+    assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=1e-4, atol=tol(ref.bias.grad))
+    if res:
+        assert torch.allclose(r.grad, r2.grad, rtol=1e-5, atol=1e-6)
+    if training:
+        assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-6)
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_resnet18_fused_bn_matches_unfused(train):
+    """Whole model: the fused path is as close to a float64 evaluation as the unfused fp32 path is (fp32 rounding
+    through 20 train-mode BN layers is ~1e-2 relative either way, so the two fp32 paths are not compared directly)."""
+    from unlearn_saliency_amd.Classification.models import model_dict
+    from unlearn_saliency_amd.conv import use_salun_convs
+    from unlearn_saliency_amd.norm import use_fused_bn
+    torch.manual_seed(0)
+    a = model_dict["resnet18"](num_classes=10).cuda()
+    b = model_dict["resnet18"](num_classes=10).cuda()
+    d = model_dict["resnet18"](num_classes=10).cuda().double()
+    b.load_state_dict(a.state_dict())
+    d.load_state_dict(a.state_dict())
+    use_salun_convs(a); use_salun_convs(b)
+    assert use_fused_bn(b) == 20
+    x = torch.rand(64, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (64,), device="cuda")
+    losses = []
+    for m, xx in ((a, x), (b, x), (d, x.double())):
+        m.train(train)
+        loss = F.cross_entropy(m(xx), y)
+        loss.backward()
+        losses.append(loss.item())
+    assert abs(losses[1] - losses[2]) <= 1e-5 * abs(losses[2])
+    worst_a = worst_b = 0.0
+    for (k, p), q, r in zip(a.named_parameters(), b.parameters(), d.parameters()):
+        den = float(r.grad.abs().max()) + 1e-12
+        worst_a = max(worst_a, float((p.grad.double() - r.grad).abs().max()) / den)
+        worst_b = max(worst_b, float((q.grad.double() - r.grad).abs().max()) / den)
+    assert worst_b < 3 * worst_a + 1e-5, (worst_a, worst_b)
+    for (k, u), v in zip(d.named_buffers(), b.buffers()):
+        assert torch.allclose(u.float(), v.float(), rtol=1e-4, atol=1e-5), k
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())

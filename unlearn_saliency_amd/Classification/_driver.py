@@ -35,6 +35,8 @@ def run(argv=None, use_mask: bool = True):
     if not args.library_conv:
         from ..conv import use_salun_convs
         use_salun_convs(model)  # convolutions on the fp32 MFMA kernels (csrc/salun_conv.hip)
+        from ..norm import use_fused_bn
+        use_fused_bn(model)  # BN(+add)+ReLU as one node (csrc/salun_norm.hip); SyncBatchNorm layers are left alone
     if ws > 1 and args.sync_bn:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
 

@@ -115,6 +115,8 @@ def main(argv=None):
     if not args.library_conv:
         from ..conv import use_salun_convs
         use_salun_convs(model)  # convolutions on the fp32 MFMA kernels (csrc/salun_conv.hip)
+        from ..norm import use_fused_bn
+        use_fused_bn(model)  # BN(+add)+ReLU as one node (csrc/salun_norm.hip); SyncBatchNorm layers are left alone
 
     def replace_loader_dataset(dataset, batch_size=args.batch_size, seed=1, shuffle=True):
         utils.setup_seed(seed)

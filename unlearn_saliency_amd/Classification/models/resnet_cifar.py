@@ -48,7 +48,14 @@ class BasicBlock(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
+    fused_bn = False  # set by unlearn_saliency_amd.norm.use_fused_bn
+
     def forward(self, x):
+        if self.fused_bn:
+            from ...norm import fused_bn_act
+            y = fused_bn_act(self.conv1(x), self.bn1, relu=True)
+            skip = x if self.downsample is None else fused_bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+            return fused_bn_act(self.conv2(y), self.bn2, residual=skip, relu=True)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         skip = x if self.downsample is None else self.downsample(x)
@@ -86,9 +93,15 @@ class ResNetCifar(nn.Module):
                 nn.init.ones_(mod.weight)
                 nn.init.zeros_(mod.bias)
 
+    fused_bn = False
+
     def forward(self, x):
         x = self.normalize(x)
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        if self.fused_bn:
+            from ...norm import fused_bn_act
+            x = self.maxpool(fused_bn_act(self.conv1(x), self.bn1, relu=True))
+        else:
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 

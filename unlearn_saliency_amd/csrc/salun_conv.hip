@@ -571,26 +571,45 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
     }
   };
 
+  // spatial offset of pixel m of the chunk inside one channel's patch (same for every chunk): a 64-entry table
+  // instead of a shift/divide chain per pixel pair in the MFMA loop
+  int *soff = reinterpret_cast<int *>(dl + 64 * DROW);  // carved from the dynamic LDS block (PIXC ints)
+  if (tid < PIXC) {
+    const int q = tid & (Q - 1), pr = tid >> logQ;
+    const int ni = pr / TP, pl = pr - ni * TP;
+    soff[tid] = (ni * IH_t + pl * STRIDE) * IW_t + q * STRIDE;
+  }
   if (split < nchunks) load_chunk(split);
+  const float *arow = dl + (kt * 32 + lo) * DROW;
+  const float *brow = xp + (ct * 32 + lo) * ch_stride;
   for (int chunk = split; chunk < nchunks; chunk += nsplit) {
     __syncthreads();
     store_chunk();
     __syncthreads();
     if (chunk + nsplit < nchunks) load_chunk(chunk + nsplit);
-    const float *arow = dl + (kt * 32 + lo) * DROW;
-    const float *brow = xp + (ct * 32 + lo) * ch_stride;
-#pragma unroll 4
-    for (int j = 0; j < PIXC; j += 2) {
+    // one-step-ahead operand pipeline: the 1 + R*R LDS operands of pixel pair i+1 are read while the R*R MFMAs
+    // of pair i run
+    auto operands = [&](int j, float &av, float (&bv)[RS]) {
       const int m = j + hi;
-      const int q = m & (Q - 1), pr = m >> logQ;
-      const int ni = pr / TP, pl = pr - ni * TP;
-      const float a = arow[m];
-      const float *bp = brow + (ni * IH_t + pl * STRIDE) * IW_t + q * STRIDE;
+      av = arow[m];
+      const float *bp = brow + soff[m];
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int s = 0; s < R; ++s)
-          acc[r * R + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[r * IW_t + s], acc[r * R + s], 0, 0, 0);
+        for (int s2 = 0; s2 < R; ++s2) bv[r * R + s2] = bp[r * IW_t + s2];
+    };
+    float a_cur, b_cur[RS], a_nxt = 0.f, b_nxt[RS];
+    operands(0, a_cur, b_cur);
+#pragma unroll
+    for (int j = 0; j < PIXC; j += 2) {
+      if (j + 2 < PIXC) operands(j + 2, a_nxt, b_nxt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < RS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a_cur = a_nxt;
+#pragma unroll
+      for (int t = 0; t < RS; ++t) b_cur[t] = b_nxt[t];
     }
   }
   // ---- partial[split][rs][k][c]: a wave's 32 result columns (c) are contiguous => coalesced 128-B stores;
@@ -886,7 +905,7 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
   if (ws_bytes < need) return SALUN_ENOSPC;
   hipStream_t st = salun_hip_stream(stream);
   const int PSZ = g.NI * g.IH_t * g.IW_t;
-  const size_t ldsb = sizeof(float) * ((size_t)64 * (PSZ | 1) + (size_t)64 * (pixc + 1));
+  const size_t ldsb = sizeof(float) * ((size_t)64 * (PSZ | 1) + (size_t)64 * (pixc + 1) + (size_t)pixc);
   if (ldsb > 160 * 1024) return SALUN_EINVAL;
   dim3 grid((K + 63) / 64, (C + 63) / 64, ns);
   float *part = static_cast<float *>(ws);

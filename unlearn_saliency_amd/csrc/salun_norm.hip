@@ -1,0 +1,279 @@
+// salun_norm.hip — fused BatchNorm2d (+ residual add) (+ ReLU), forward and backward, NCHW fp32.
+//
+// ResNet's BN / ReLU / residual-add chain is pure HBM traffic: as separate library launches it makes ~19 passes over
+// every activation tensor per training step (profiles/r01_bench_kernel_stats.csv: 2.65 of 14.1 ms).  Fused:
+//   forward   stats (1 read)                      -> mean, invstd (+ running stats update)
+//             apply (1-2 reads, 1 write)          y = relu(gamma*(x-mean)*invstd + beta + residual)
+//   backward  reduce (3 reads)                    dbeta = sum dz, dgamma = sum dz*xhat,  dz = dy * [y > 0]
+//             apply (3 reads, 1-2 writes)         dx = gamma*invstd*(dz - (dbeta + xhat*dgamma)/M)   (train)
+//                                                 dx = gamma*invstd*dz                               (eval)
+//                                                 dres = dz
+// Reductions: per (channel, slice-of-batch) workgroup partials in fp64, folded in a fixed order (deterministic).
+// Semantics follow torch.nn.BatchNorm2d (biased variance for normalisation, unbiased for running_var, momentum).
+#include "salun_common.h"
+
+namespace {
+
+constexpr int BN_MAX_SPLIT = 64;
+
+// partial[(c*nsplit + s)*2 + {0,1}]: sums over images n in slice s of channel c
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float *__restrict__ x, int N, int C, int HW, int nsplit,
+                                                          double *__restrict__ partial) {
+  __shared__ double lds[4];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int n_lo = (int)((int64_t)N * s / nsplit), n_hi = (int)((int64_t)N * (s + 1) / nsplit);
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;
+  const int hw4 = HW >> 2;
+  const int work = (n_hi - n_lo) * hw4;  // float4 items of this (channel, slice): all lanes busy even for 4x4 maps
+  int it = 0;
+  for (int e = threadIdx.x; e < work; e += 256, ++it) {
+    const int n = n_lo + e / hw4, i = e - (e / hw4) * hw4;
+    const float4 v = reinterpret_cast<const float4 *>(x + ((size_t)n * C + c) * HW)[i];
+    s1 += (v.x + v.y) + (v.z + v.w);
+    s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    if ((it & 7) == 7) { d1 += s1; d2 += s2; s1 = 0.f; s2 = 0.f; }  // bound fp32 accumulation length
+  }
+  d1 += s1; d2 += s2;
+  const double t1 = salun_block_sum(d1, lds);
+  const double t2 = salun_block_sum(d2, lds);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * nsplit + s) * 2 + 0] = t1;
+    partial[((size_t)c * nsplit + s) * 2 + 1] = t2;
+  }
+}
+
+__global__ void k_bn_stats_final(const double *__restrict__ partial, int C, int nsplit, double M, float eps,
+                                 float momentum, float *__restrict__ mean, float *__restrict__ invstd,
+                                 float *__restrict__ running_mean, float *__restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    s1 += partial[((size_t)c * nsplit + s) * 2 + 0];
+    s2 += partial[((size_t)c * nsplit + s) * 2 + 1];
+  }
+  const double mu = s1 / M;
+  double var = s2 / M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    const double unbiased = (M > 1.0) ? var * M / (M - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval mode: mean / invstd from the running statistics
+__global__ void k_bn_eval_params(const float *__restrict__ running_mean, const float *__restrict__ running_var, int C,
+                                 float eps, float *__restrict__ mean, float *__restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, const float *__restrict__ res,
+                                                  float *__restrict__ y, const float *__restrict__ mean,
+                                                  const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                  const float *__restrict__ beta, int C, int HW, int64_t total4) {
+  const int hw4 = HW >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i / hw4) % C);
+    const float a = invstd[c] * gamma[c];
+    const float b = beta[c] - mean[c] * a;
+    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    float4 o;
+    o.x = v.x * a + b; o.y = v.y * a + b; o.z = v.z * a + b; o.w = v.w * a + b;
+    if (RES) {
+      const float4 r = reinterpret_cast<const float4 *>(res)[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (RELU) {
+      o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+      o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+    }
+    reinterpret_cast<float4 *>(y)[i] = o;
+  }
+}
+
+// partial[(c*nsplit + s)*2 + {0: sum dz, 1: sum dz*xhat}]
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict__ dy, const float *__restrict__ y,
+                                                        const float *__restrict__ x, const float *__restrict__ mean,
+                                                        const float *__restrict__ invstd, int N, int C, int HW,
+                                                        int nsplit, double *__restrict__ partial) {
+  __shared__ double lds[4];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int n_lo = (int)((int64_t)N * s / nsplit), n_hi = (int)((int64_t)N * (s + 1) / nsplit);
+  const float mu = mean[c], is = invstd[c];
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;
+  const int hw4 = HW >> 2;
+  const int work = (n_hi - n_lo) * hw4;
+  int it = 0;
+  for (int e = threadIdx.x; e < work; e += 256, ++it) {
+    const int n = n_lo + e / hw4, i = e - (e / hw4) * hw4;
+    const size_t off = ((size_t)n * C + c) * HW;
+    float4 g = reinterpret_cast<const float4 *>(dy + off)[i];
+    const float4 xv = reinterpret_cast<const float4 *>(x + off)[i];
+    if (RELU) {
+      const float4 yv = reinterpret_cast<const float4 *>(y + off)[i];
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    s1 += (g.x + g.y) + (g.z + g.w);
+    s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) + (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
+    if ((it & 7) == 7) { d1 += s1; d2 += s2; s1 = 0.f; s2 = 0.f; }
+  }
+  d1 += s1; d2 += s2;
+  const double t1 = salun_block_sum(d1, lds);
+  const double t2 = salun_block_sum(d2, lds);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * nsplit + s) * 2 + 0] = t1;
+    partial[((size_t)c * nsplit + s) * 2 + 1] = t2;
+  }
+}
+
+__global__ void k_bn_bwd_final(const double *__restrict__ partial, int C, int nsplit, float *__restrict__ dgamma,
+                               float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    s1 += partial[((size_t)c * nsplit + s) * 2 + 0];
+    s2 += partial[((size_t)c * nsplit + s) * 2 + 1];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+}
+
+template <bool RELU, bool TRAIN, bool DRES>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
+                                                      const float *__restrict__ x, const float *__restrict__ mean,
+                                                      const float *__restrict__ invstd,
+                                                      const float *__restrict__ gamma,
+                                                      const float *__restrict__ dgamma,
+                                                      const float *__restrict__ dbeta, float *__restrict__ dx,
+                                                      float *__restrict__ dres, int C, int HW, float inv_m,
+                                                      int64_t total4) {
+  const int hw4 = HW >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i / hw4) % C);
+    const float mu = mean[c], is = invstd[c];
+    const float gi = gamma[c] * is;
+    float4 g = reinterpret_cast<const float4 *>(dy)[i];
+    if (RELU) {
+      const float4 yv = reinterpret_cast<const float4 *>(y)[i];
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    if (DRES) reinterpret_cast<float4 *>(dres)[i] = g;
+    float4 o;
+    if (TRAIN) {
+      const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+      const float kb = dbeta[c] * inv_m, kg = dgamma[c] * inv_m;
+      o.x = gi * (g.x - (kb + ((xv.x - mu) * is) * kg));
+      o.y = gi * (g.y - (kb + ((xv.y - mu) * is) * kg));
+      o.z = gi * (g.z - (kb + ((xv.z - mu) * is) * kg));
+      o.w = gi * (g.w - (kb + ((xv.w - mu) * is) * kg));
+    } else {
+      o.x = gi * g.x; o.y = gi * g.y; o.z = gi * g.z; o.w = gi * g.w;
+    }
+    reinterpret_cast<float4 *>(dx)[i] = o;
+  }
+}
+
+inline int bn_nsplit(int N, int C) {
+  int ns = (1024 + C - 1) / C;  // aim for >= ~1024 workgroups
+  if (ns > N) ns = N;
+  if (ns > BN_MAX_SPLIT) ns = BN_MAX_SPLIT;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+
+}  // namespace
+
+// ================================================================== C-ABI =======
+SALUN_EXPORT size_t salun_bn_workspace_bytes(int C) {
+  return sizeof(double) * 2 * (size_t)(C > 0 ? C : 0) * BN_MAX_SPLIT;
+}
+
+// training != 0: batch statistics -> mean/invstd (saved for backward) and running-stat update (if pointers given);
+// training == 0: mean/invstd from the running statistics.  Then y = [relu](gamma*(x-mean)*invstd + beta [+ res]).
+SALUN_EXPORT int salun_bn_forward(const float *x, const float *res, float *y, const float *gamma, const float *beta,
+                                  float *running_mean, float *running_var, float *save_mean, float *save_invstd,
+                                  int N, int C, int HW, int training, double momentum, double eps, int relu, void *ws,
+                                  size_t ws_bytes, salun_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || N < 1 || C < 1 || HW < 4 || (HW & 3))
+    return SALUN_EINVAL;
+  if (!training && (!running_mean || !running_var)) return SALUN_EINVAL;
+  if (!salun_aligned16(x) || !salun_aligned16(y) || (res && !salun_aligned16(res))) return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  if (training) {
+    if (!ws || ws_bytes < salun_bn_workspace_bytes(C)) return SALUN_ENOSPC;
+    const int ns = bn_nsplit(N, C);
+    double *partial = static_cast<double *>(ws);
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3(C, ns), dim3(256), 0, st, x, N, C, HW, ns, partial);
+    SALUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, st, partial, C, ns, (double)N * HW,
+                       (float)eps, (float)momentum, save_mean, save_invstd, running_mean, running_var);
+    SALUN_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(k_bn_eval_params, dim3((C + 255) / 256), dim3(256), 0, st, running_mean, running_var, C,
+                       (float)eps, save_mean, save_invstd);
+    SALUN_LAUNCH_CHECK();
+  }
+  const int64_t total4 = (int64_t)N * C * HW / 4;
+  const int grid = salun_grid_for(total4, 256 * 4);
+#define SALUN_BN_APPLY(RELU_, RES_) \
+  hipLaunchKernelGGL((k_bn_apply<RELU_, RES_>), dim3(grid), dim3(256), 0, st, x, res, y, save_mean, save_invstd, gamma, beta, C, HW, total4)
+  if (relu && res) SALUN_BN_APPLY(true, true);
+  else if (relu) SALUN_BN_APPLY(true, false);
+  else if (res) SALUN_BN_APPLY(false, true);
+  else SALUN_BN_APPLY(false, false);
+#undef SALUN_BN_APPLY
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+// dgamma, dbeta always; dx; dres (= dz, gradient of the residual input) if non-NULL.
+SALUN_EXPORT int salun_bn_backward(const float *dy, const float *y, const float *x, const float *gamma,
+                                   const float *save_mean, const float *save_invstd, float *dx, float *dres,
+                                   float *dgamma, float *dbeta, int N, int C, int HW, int training, int relu,
+                                   void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || N < 1 || C < 1 || HW < 4 ||
+      (HW & 3) || (relu && !y))
+    return SALUN_EINVAL;
+  if (!ws || ws_bytes < salun_bn_workspace_bytes(C)) return SALUN_ENOSPC;
+  if (!salun_aligned16(dy) || !salun_aligned16(x) || !salun_aligned16(dx) || (y && !salun_aligned16(y)) ||
+      (dres && !salun_aligned16(dres)))
+    return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  const int ns = bn_nsplit(N, C);
+  double *partial = static_cast<double *>(ws);
+  if (relu) hipLaunchKernelGGL(k_bn_bwd_partial<true>, dim3(C, ns), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, N, C, HW, ns, partial);
+  else hipLaunchKernelGGL(k_bn_bwd_partial<false>, dim3(C, ns), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, N, C, HW, ns, partial);
+  SALUN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, partial, C, ns, dgamma, dbeta);
+  SALUN_LAUNCH_CHECK();
+  const int64_t total4 = (int64_t)N * C * HW / 4;
+  const int grid = salun_grid_for(total4, 256 * 4);
+  const float inv_m = (float)(1.0 / ((double)N * HW));
+#define SALUN_BN_BWD(RELU_, TRAIN_, DRES_) \
+  hipLaunchKernelGGL((k_bn_bwd_apply<RELU_, TRAIN_, DRES_>), dim3(grid), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, dgamma, dbeta, dx, dres, C, HW, inv_m, total4)
+  const bool r = relu != 0, t = training != 0, d = dres != nullptr;
+  if (r && t && d) SALUN_BN_BWD(true, true, true);
+  else if (r && t) SALUN_BN_BWD(true, true, false);
+  else if (r && d) SALUN_BN_BWD(true, false, true);
+  else if (r) SALUN_BN_BWD(true, false, false);
+  else if (t && d) SALUN_BN_BWD(false, true, true);
+  else if (t) SALUN_BN_BWD(false, true, false);
+  else if (d) SALUN_BN_BWD(false, false, true);
+  else SALUN_BN_BWD(false, false, false);
+#undef SALUN_BN_BWD
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}

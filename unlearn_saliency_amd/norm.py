@@ -1,0 +1,71 @@
+"""Fused BatchNorm2d (+ residual add) (+ ReLU) on the kernels of csrc/salun_norm.hip.
+
+`fused_bn_act(x, bn, residual=None, relu=True)` runs an `nn.BatchNorm2d` module's math (its parameters, running
+statistics, momentum, eps, train/eval mode) plus the optional residual add and ReLU that follow it in a
+ResNet block as ONE autograd node: 2 forward + 2 backward streaming launches (+ two tiny finalisers) instead of
+the library's BN kernels, a ReLU, an add, a ReLU-backward and a gradient add — about half the HBM passes.
+`use_fused_bn(model)` switches the CIFAR ResNet blocks of this package to it; state_dict is unchanged.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _FusedBN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
+        out = ops.bn_forward(x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu)
+        if out is None:
+            raise RuntimeError("fused BN: unsupported shape (H*W must be a multiple of 4)")
+        y, mean, invstd = out
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.cfg = (bool(training), bool(relu), residual is not None)
+        ctx.mark_non_differentiable(mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        dx, dres, dgamma, dbeta = ops.bn_backward(dy.contiguous(), y, x, weight, mean, invstd, training, relu,
+                                                  has_res and ctx.needs_input_grad[3])
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def _eligible(x: torch.Tensor, bn: nn.BatchNorm2d) -> bool:
+    return (type(bn) is nn.BatchNorm2d and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (x.shape[2] * x.shape[3]) % 4 == 0
+            and bn.affine and bn.track_running_stats and bn.momentum is not None and not torch.is_autocast_enabled())
+
+
+def fused_bn_act(x: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor = None, relu: bool = True):
+    if not _eligible(x, bn):
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    if bn.training:
+        bn.num_batches_tracked.add_(1)
+    return _FusedBN.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.training,
+                          bn.momentum, bn.eps, relu)
+
+
+def use_fused_bn(model: nn.Module) -> int:
+    """Switch this package's CIFAR ResNet (stem + BasicBlocks) to the fused BN path.  Returns the number of
+    BatchNorm layers covered."""
+    from .Classification.models import resnet_cifar as R
+    n = 0
+    for mod in model.modules():
+        if isinstance(mod, R.BasicBlock):
+            mod.fused_bn = True
+            n += 2 + (1 if mod.downsample is not None else 0)
+        elif isinstance(mod, R.ResNetCifar):
+            mod.fused_bn = True
+            n += 1
+    return n

@@ -260,6 +260,46 @@ def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: i
     return dw
 
 
+# ------------------------------------------------------------------- fused BatchNorm
+def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    """-> (y, save_mean, save_invstd) or None when the shape is outside the kernel's domain (HW % 4 != 0)."""
+    N, C, H, W = x.shape
+    L = _lib.lib()
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(L.salun_bn_workspace_bytes(C), x.device)
+    rc = L.salun_bn_forward(_dev(x, torch.float32, "x"), _dev(res, torch.float32, "res", True), c_void_p(y.data_ptr()),
+                            _dev(gamma, torch.float32, "weight"), _dev(beta, torch.float32, "bias"),
+                            _dev(running_mean, torch.float32, "running_mean", True),
+                            _dev(running_var, torch.float32, "running_var", True), c_void_p(mean.data_ptr()),
+                            c_void_p(invstd.data_ptr()), N, C, H * W, int(bool(training)), c_double(momentum),
+                            c_double(eps), int(bool(relu)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream())
+    if rc == _lib.SALUN_EINVAL:
+        return None
+    check(rc, "salun_bn_forward")
+    return y, mean, invstd
+
+
+def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, want_dres):
+    """-> (dx, dres or None, dgamma, dbeta)."""
+    N, C, H, W = x.shape
+    L = _lib.lib()
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(L.salun_bn_workspace_bytes(C), x.device)
+    check(L.salun_bn_backward(_dev(dy, torch.float32, "dy"), _dev(y, torch.float32, "y", True),
+                              _dev(x, torch.float32, "x"), _dev(gamma, torch.float32, "weight"),
+                              _dev(mean, torch.float32, "mean"), _dev(invstd, torch.float32, "invstd"),
+                              c_void_p(dx.data_ptr()), _dev(dres, torch.float32, "dres", True),
+                              c_void_p(dgamma.data_ptr()), c_void_p(dbeta.data_ptr()), N, C, H * W,
+                              int(bool(training)), int(bool(relu)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()),
+                              _stream()), "salun_bn_backward")
+    return dx, dres, dgamma, dbeta
+
+
 # ----------------------------------------------------------------------------- K0
 def image_batch(data: torch.Tensor, idx: torch.Tensor, crop: Optional[torch.Tensor] = None,
                 flip: Optional[torch.Tensor] = None, pad: int = 4, out: Optional[torch.Tensor] = None) -> torch.Tensor:

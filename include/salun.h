@@ -206,6 +206,11 @@ int salun_conv2d_forward(const float *x /*dev*/, const float *w /*dev*/, const f
 int salun_conv2d_backward_data(const float *dy /*dev*/, const float *w /*dev*/, float *dx /*dev*/, int N, int C,
                                int H, int W, int K, int R, int stride, int pad, int P, int Q,
                                salun_stream_t stream);
+/* dx = backward_data(dy, w) + addend  (addend: [N,C,H,W] or NULL; addend == dx accumulates in place).  The residual
+ * branch's gradient of a ResNet block is folded into the convolution's epilogue instead of a separate add pass. */
+int salun_conv2d_backward_data_add(const float *dy /*dev*/, const float *w /*dev*/, const float *addend /*dev or NULL*/,
+                                   float *dx /*dev*/, int N, int C, int H, int W, int K, int R, int stride, int pad,
+                                   int P, int Q, salun_stream_t stream);
 size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int R, int P, int Q);
 int salun_conv2d_backward_weight(const float *x /*dev*/, const float *dy /*dev*/, float *dw /*dev*/, int N, int C,
                                  int H, int W, int K, int R, int stride, int pad, int P, int Q, int accumulate,
@@ -231,6 +236,7 @@ int salun_bn_forward(const float *x /*dev*/, const float *res /*dev or NULL*/, f
 int salun_bn_backward(const float *dy /*dev*/, const float *y /*dev, needed if relu*/, const float *x /*dev*/,
                       const float *gamma /*dev*/, const float *save_mean /*dev*/, const float *save_invstd /*dev*/,
                       float *dx /*dev*/, float *dres /*dev or NULL*/, float *dgamma /*dev*/, float *dbeta /*dev*/,
+                      float *grad_gamma_acc /*dev or NULL: += dgamma*/, float *grad_beta_acc /*dev or NULL: += dbeta*/,
                       int N, int C, int HW, int training, int relu, void *ws /*dev*/, size_t ws_bytes,
                       salun_stream_t stream);
 

@@ -49,8 +49,9 @@ def test_fused_bn_matches_torch(shape, training, relu, res):
         assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("blocks", [False, True])
 @pytest.mark.parametrize("train", [True, False])
-def test_resnet18_fused_bn_matches_unfused(train):
+def test_resnet18_fused_bn_matches_unfused(train, blocks):
     """Whole model: the fused path is as close to a float64 evaluation as the unfused fp32 path is (fp32 rounding
     through 20 train-mode BN layers is ~1e-2 relative either way, so the two fp32 paths are not compared directly)."""
     from unlearn_saliency_amd.Classification.models import model_dict
@@ -63,7 +64,7 @@ def test_resnet18_fused_bn_matches_unfused(train):
     b.load_state_dict(a.state_dict())
     d.load_state_dict(a.state_dict())
     use_salun_convs(a); use_salun_convs(b)
-    assert use_fused_bn(b) == 20
+    assert use_fused_bn(b, blocks=blocks) == 20
     x = torch.rand(64, 3, 32, 32, device="cuda")
     y = torch.randint(0, 10, (64,), device="cuda")
     losses = []
@@ -82,3 +83,55 @@ def test_resnet18_fused_bn_matches_unfused(train):
     for (k, u), v in zip(d.named_buffers(), b.buffers()):
         assert torch.allclose(u.float(), v.float(), rtol=1e-4, atol=1e-5), k
     assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 64, 3, 1, 1, 32), (8, 64, 128, 3, 2, 1, 32), (8, 64, 128, 1, 2, 0, 32),
+                                   (4, 256, 512, 3, 2, 1, 8), (4, 512, 512, 3, 1, 1, 4)])
+def test_backward_data_addend_is_a_fused_add(shape):
+    """dx = dgrad(dy, w) + addend, bit-identical to the separate add (one fp32 add per element either way)."""
+    from unlearn_saliency_amd import ops
+    N, C, K, R, s, pad, H = shape
+    torch.manual_seed(1)
+    P = (H + 2 * pad - R) // s + 1
+    dy = torch.randn(N, K, P, P, device="cuda")
+    w = torch.randn(K, C, R, R, device="cuda") * 0.05
+    add = torch.randn(N, C, H, H, device="cuda")
+    base = ops.conv2d_backward_data(dy, w, (N, C, H, H), s, pad)
+    fused = ops.conv2d_backward_data(dy, w, (N, C, H, H), s, pad, addend=add)
+    assert base is not None and fused is not None
+    assert torch.equal(fused, base + add)
+
+
+def test_direct_grad_accumulation_equals_autograd_route():
+    """Kernels adding into .grad (gradsink) == returning gradients for AccumulateGrad, over two accumulating
+    backward passes; post-accumulate hooks fire once per parameter per backward either way."""
+    from unlearn_saliency_amd import gradsink
+    from unlearn_saliency_amd.Classification.models import model_dict
+    from unlearn_saliency_amd.conv import use_salun_convs
+    from unlearn_saliency_amd.flat import FlatArena
+    from unlearn_saliency_amd.norm import use_fused_bn
+    torch.manual_seed(0)
+    x = torch.rand(32, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (32,), device="cuda")
+    results = []
+    for direct in (True, False):
+        torch.manual_seed(0)
+        m = model_dict["resnet18"](num_classes=10).cuda()
+        use_salun_convs(m); use_fused_bn(m)
+        m.eval()  # deterministic forward across the two passes
+        arena = FlatArena.from_module(m)
+        fired = {}
+        for n, p in m.named_parameters():
+            p.register_post_accumulate_grad_hook(lambda _p, n=n: fired.__setitem__(n, fired.get(n, 0) + 1))
+        gradsink.enable(direct)
+        try:
+            arena.zero_grad()
+            for _ in range(2):
+                F.cross_entropy(m(x), y).backward()
+        finally:
+            gradsink.enable(True)
+        assert set(fired) == {n for n, _ in m.named_parameters()}
+        assert set(fired.values()) == {2}, (direct, {n: c for n, c in fired.items() if c != 2})
+        results.append(arena.grads.clone())
+    a, b = results
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))

@@ -49,8 +49,14 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     fused_bn = False  # set by unlearn_saliency_amd.norm.use_fused_bn
+    fused_block = False  # set by use_fused_bn(model, blocks=True): the whole block as one autograd node
 
     def forward(self, x):
+        if self.fused_block:
+            from ...resblock import fused_basic_block
+            out = fused_basic_block(self, x)
+            if out is not None:
+                return out
         if self.fused_bn:
             from ...norm import fused_bn_act
             y = fused_bn_act(self.conv1(x), self.bn1, relu=True)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import gradsink, ops
 
 
 def _eligible(mod: nn.Conv2d) -> bool:
@@ -46,9 +46,13 @@ class _ConvFn(torch.autograd.Function):
             if dx is None:
                 dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad) if ctx.native else None
+            dst = gradsink.sink(w) if ctx.native else None
+            dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad, out=dst, accumulate=True) if ctx.native else None
             if dw is None:
                 dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
+            elif dst is not None:  # already added into w.grad by the kernel
+                gradsink.arrived(w)
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None

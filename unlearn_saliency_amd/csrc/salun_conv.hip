@@ -285,8 +285,9 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
         const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
         if (k < yC) {
           float o = acc[t][v];
-          if (bias) o += bias[k];
-          y[(((size_t)n_out * yC + k) * P + p_out) * Q + q_l] = o;
+          const size_t oi = (((size_t)n_out * yC + k) * P + p_out) * Q + q_l;
+          if (bias) o += DGRAD ? bias[oi] : bias[k];  // backward-data: `bias` is a full-size addend (may alias y)
+          y[oi] = o;
         }
       }
     }
@@ -479,8 +480,9 @@ __global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
         const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
         if (k < g.yC) {
           float o = acc[t][v];
-          if (g.bias) o += g.bias[k];
-          g.y[(((size_t)n_out * g.yC + k) * g.yH + h_out) * g.yW + w_out] = o;
+          const size_t oi = (((size_t)n_out * g.yC + k) * g.yH + h_out) * g.yW + w_out;
+          if (g.bias) o += DGRAD ? g.bias[oi] : g.bias[k];
+          g.y[oi] = o;
         }
       }
     }
@@ -801,16 +803,16 @@ int launch_igemm_tap(IgemmArgs a, hipStream_t st) {
 
 // backward-data: one launch for stride 1, one launch per output parity class for stride 2
 template <int R>
-int launch_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H, int W, int K, int stride, int pad,
-                 int P, int Q, hipStream_t st) {
+int launch_dgrad(const float *dy, const float *w, const float *addend, float *dx, int N, int C, int H, int W, int K,
+                 int stride, int pad, int P, int Q, hipStream_t st) {
   IgemmArgs a{};
-  a.x = dy; a.w = w; a.bias = nullptr; a.y = dx;
+  a.x = dy; a.w = w; a.bias = addend; a.y = dx;
   a.N = N; a.xC = K; a.xH = P; a.xW = Q; a.yC = C; a.yH = H; a.yW = W;
   a.wC = C; a.wK = K; a.Rfull = R;
   if (stride == 1) {
     a.subH = H; a.subW = W; a.os = 1; a.ph = a.pw = 0;
     a.rtop_h = a.rtop_w = R - 1; a.ts = 1;
-    return launch_igemm<R, 1, true>(dy, w, nullptr, dx, N, K, P, Q, C, H, W, pad, C, K, st);
+    return launch_igemm<R, 1, true>(dy, w, addend, dx, N, K, P, Q, C, H, W, pad, C, K, st);
   }
   if ((H & 1) || (W & 1)) return SALUN_EINVAL;
   a.subH = H / 2; a.subW = W / 2; a.os = 2; a.ts = 2;
@@ -825,7 +827,15 @@ int launch_dgrad(const float *dy, const float *w, float *dx, int N, int C, int H
   for (int ph = 0; ph < 2; ++ph)
     for (int pw = 0; pw < 2; ++pw)
       if (ntap[ph] == 0 || ntap[pw] == 0) any_empty = true;
-  if (any_empty && hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * C * H * W, st) != hipSuccess) return SALUN_EIO;
+  if (any_empty) {  // positions no tap reaches: 0, or the addend itself
+    const size_t bytes = sizeof(float) * (size_t)N * C * H * W;
+    if (!addend) {
+      if (hipMemsetAsync(dx, 0, bytes, st) != hipSuccess) return SALUN_EIO;
+    } else if (addend != dx) {
+      if (hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return SALUN_EIO;
+      a.bias = dx;  // the covered classes now accumulate in place
+    }
+  }
   for (int ph = 0; ph < 2; ++ph)
     for (int pw = 0; pw < 2; ++pw) {
       if (ntap[ph] == 0 || ntap[pw] == 0) continue;
@@ -870,16 +880,22 @@ SALUN_EXPORT int salun_conv2d_forward(const float *x, const float *w, const floa
   return SALUN_EINVAL;
 }
 
-// dx[N,C,H,W] = conv2d_backward_data(dy[N,K,P,Q], w[K,C,R,R])
-SALUN_EXPORT int salun_conv2d_backward_data(const float *dy, const float *w, float *dx, int N, int C, int H, int W,
-                                            int K, int R, int stride, int pad, int P, int Q,
-                                            salun_stream_t stream) {
+// dx[N,C,H,W] = conv2d_backward_data(dy[N,K,P,Q], w[K,C,R,R]) (+ addend[N,C,H,W]; addend == dx accumulates in place)
+SALUN_EXPORT int salun_conv2d_backward_data_add(const float *dy, const float *w, const float *addend, float *dx, int N,
+                                                int C, int H, int W, int K, int R, int stride, int pad, int P, int Q,
+                                                salun_stream_t stream) {
   if (!dy || !w || !dx || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
   if (stride != 1 && stride != 2) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
-  if (R == 3) return launch_dgrad<3>(dy, w, dx, N, C, H, W, K, stride, pad, P, Q, st);
-  if (R == 1) return launch_dgrad<1>(dy, w, dx, N, C, H, W, K, stride, pad, P, Q, st);
+  if (R == 3) return launch_dgrad<3>(dy, w, addend, dx, N, C, H, W, K, stride, pad, P, Q, st);
+  if (R == 1) return launch_dgrad<1>(dy, w, addend, dx, N, C, H, W, K, stride, pad, P, Q, st);
   return SALUN_EINVAL;
+}
+
+SALUN_EXPORT int salun_conv2d_backward_data(const float *dy, const float *w, float *dx, int N, int C, int H, int W,
+                                            int K, int R, int stride, int pad, int P, int Q,
+                                            salun_stream_t stream) {
+  return salun_conv2d_backward_data_add(dy, w, nullptr, dx, N, C, H, W, K, R, stride, pad, P, Q, stream);
 }
 
 SALUN_EXPORT size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int R, int P, int Q) {

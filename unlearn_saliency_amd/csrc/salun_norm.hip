@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict_
 }
 
 __global__ void k_bn_bwd_final(const double *__restrict__ partial, int C, int nsplit, float *__restrict__ dgamma,
-                               float *__restrict__ dbeta) {
+                               float *__restrict__ dbeta, float *__restrict__ gacc, float *__restrict__ bacc) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
@@ -148,6 +148,8 @@ __global__ void k_bn_bwd_final(const double *__restrict__ partial, int C, int ns
   }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
+  if (gacc) gacc[c] += (float)s2;  // optional: accumulate straight into the parameters' .grad storage
+  if (bacc) bacc[c] += (float)s1;
 }
 
 template <bool RELU, bool TRAIN, bool DRES>
@@ -239,11 +241,12 @@ SALUN_EXPORT int salun_bn_forward(const float *x, const float *res, float *y, co
   return SALUN_OK;
 }
 
-// dgamma, dbeta always; dx; dres (= dz, gradient of the residual input) if non-NULL.
+// dgamma, dbeta always (this call's values); grad_*_acc (optional) += them; dx; dres (= dz) if non-NULL.
 SALUN_EXPORT int salun_bn_backward(const float *dy, const float *y, const float *x, const float *gamma,
                                    const float *save_mean, const float *save_invstd, float *dx, float *dres,
-                                   float *dgamma, float *dbeta, int N, int C, int HW, int training, int relu,
-                                   void *ws, size_t ws_bytes, salun_stream_t stream) {
+                                   float *dgamma, float *dbeta, float *grad_gamma_acc, float *grad_beta_acc, int N,
+                                   int C, int HW, int training, int relu, void *ws, size_t ws_bytes,
+                                   salun_stream_t stream) {
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || N < 1 || C < 1 || HW < 4 ||
       (HW & 3) || (relu && !y))
     return SALUN_EINVAL;
@@ -257,7 +260,8 @@ SALUN_EXPORT int salun_bn_backward(const float *dy, const float *y, const float 
   if (relu) hipLaunchKernelGGL(k_bn_bwd_partial<true>, dim3(C, ns), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, N, C, HW, ns, partial);
   else hipLaunchKernelGGL(k_bn_bwd_partial<false>, dim3(C, ns), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, N, C, HW, ns, partial);
   SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, partial, C, ns, dgamma, dbeta);
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, partial, C, ns, dgamma, dbeta,
+                     grad_gamma_acc, grad_beta_acc);
   SALUN_LAUNCH_CHECK();
   const int64_t total4 = (int64_t)N * C * HW / 4;
   const int grid = salun_grid_for(total4, 256 * 4);

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import gradsink, ops
 
 
 class _FusedBN(torch.autograd.Function):
@@ -22,17 +22,24 @@ class _FusedBN(torch.autograd.Function):
         if out is None:
             raise RuntimeError("fused BN: unsupported shape (H*W must be a multiple of 4)")
         y, mean, invstd = out
-        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.save_for_backward(x, y if relu else None, weight, bias, mean, invstd)
         ctx.cfg = (bool(training), bool(relu), residual is not None)
         ctx.mark_non_differentiable(mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, bias, mean, invstd = ctx.saved_tensors
         training, relu, has_res = ctx.cfg
+        gw, gb = gradsink.sink(weight), gradsink.sink(bias)
+        if gw is None or gb is None:
+            gw = gb = None
         dx, dres, dgamma, dbeta = ops.bn_backward(dy.contiguous(), y, x, weight, mean, invstd, training, relu,
-                                                  has_res and ctx.needs_input_grad[3])
+                                                  has_res and ctx.needs_input_grad[3], gw, gb)
+        if gw is not None:
+            gradsink.arrived(weight)
+            gradsink.arrived(bias)
+            dgamma = dbeta = None
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
@@ -56,14 +63,15 @@ def fused_bn_act(x: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor = N
                           bn.momentum, bn.eps, relu)
 
 
-def use_fused_bn(model: nn.Module) -> int:
-    """Switch this package's CIFAR ResNet (stem + BasicBlocks) to the fused BN path.  Returns the number of
-    BatchNorm layers covered."""
+def use_fused_bn(model: nn.Module, blocks: bool = True) -> int:
+    """Switch this package's CIFAR ResNet (stem + BasicBlocks) to the fused BN path; with `blocks` each BasicBlock
+    additionally runs as one autograd node (resblock.py).  Returns the number of BatchNorm layers covered."""
     from .Classification.models import resnet_cifar as R
     n = 0
     for mod in model.modules():
         if isinstance(mod, R.BasicBlock):
             mod.fused_bn = True
+            mod.fused_block = bool(blocks)
             n += 2 + (1 if mod.downsample is not None else 0)
         elif isinstance(mod, R.ResNetCifar):
             mod.fused_bn = True

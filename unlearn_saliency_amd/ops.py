@@ -226,22 +226,27 @@ def conv2d_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     return y
 
 
-def conv2d_backward_data(dy: torch.Tensor, w: torch.Tensor, x_shape, stride: int, pad: int) -> Optional[torch.Tensor]:
+def conv2d_backward_data(dy: torch.Tensor, w: torch.Tensor, x_shape, stride: int, pad: int,
+                         addend: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """dx = backward_data(dy, w) (+ addend, folded into the epilogue); None outside the tiling domain."""
     N, C, H, W = x_shape
     K, _, R, _ = w.shape
     P, Q = dy.shape[2], dy.shape[3]
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
-    rc = _lib.lib().salun_conv2d_backward_data(_dev(dy, torch.float32, "dy"), _dev(w, torch.float32, "w"),
-                                               c_void_p(dx.data_ptr()), N, C, H, W, K, R, stride, pad, P, Q,
-                                               _stream())
+    rc = _lib.lib().salun_conv2d_backward_data_add(_dev(dy, torch.float32, "dy"), _dev(w, torch.float32, "w"),
+                                                   _dev(addend, torch.float32, "addend", True),
+                                                   c_void_p(dx.data_ptr()), N, C, H, W, K, R, stride, pad, P, Q,
+                                                   _stream())
     if rc == _lib.SALUN_EINVAL:
         return None
     check(rc, "salun_conv2d_backward_data")
     return dx
 
 
-def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: int, pad: int
-                           ) -> Optional[torch.Tensor]:
+def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: int, pad: int,
+                           out: Optional[torch.Tensor] = None, accumulate: bool = False) -> Optional[torch.Tensor]:
+    """dw = backward_weight(x, dy); with `out` the result is written (accumulate=False) or added
+    (accumulate=True) into that tensor — e.g. the parameter's slice of the flat gradient arena."""
     N, C, H, W = x.shape
     K, _, R, _ = w_shape
     P, Q = dy.shape[2], dy.shape[3]
@@ -250,9 +255,10 @@ def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: i
     if nbytes == 0:
         return None
     ws = workspace(nbytes, x.device)
-    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     rc = L.salun_conv2d_backward_weight(_dev(x, torch.float32, "x"), _dev(dy, torch.float32, "dy"),
-                                        c_void_p(dw.data_ptr()), N, C, H, W, K, R, stride, pad, P, Q, 0,
+                                        _dev(dw, torch.float32, "dw"), N, C, H, W, K, R, stride, pad, P, Q,
+                                        int(bool(accumulate and out is not None)),
                                         c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream())
     if rc == _lib.SALUN_EINVAL:
         return None
@@ -281,8 +287,8 @@ def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentu
     return y, mean, invstd
 
 
-def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, want_dres):
-    """-> (dx, dres or None, dgamma, dbeta)."""
+def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, want_dres, gamma_grad_acc=None, beta_grad_acc=None):
+    """-> (dx, dres or None, dgamma, dbeta); `*_grad_acc` (optional) += dgamma / dbeta in the same launch."""
     N, C, H, W = x.shape
     L = _lib.lib()
     dx = torch.empty_like(x)
@@ -294,7 +300,9 @@ def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, want_dres):
                               _dev(x, torch.float32, "x"), _dev(gamma, torch.float32, "weight"),
                               _dev(mean, torch.float32, "mean"), _dev(invstd, torch.float32, "invstd"),
                               c_void_p(dx.data_ptr()), _dev(dres, torch.float32, "dres", True),
-                              c_void_p(dgamma.data_ptr()), c_void_p(dbeta.data_ptr()), N, C, H * W,
+                              c_void_p(dgamma.data_ptr()), c_void_p(dbeta.data_ptr()),
+                              _dev(gamma_grad_acc, torch.float32, "gamma.grad", True),
+                              _dev(beta_grad_acc, torch.float32, "beta.grad", True), N, C, H * W,
                               int(bool(training)), int(bool(relu)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()),
                               _stream()), "salun_bn_backward")
     return dx, dres, dgamma, dbeta

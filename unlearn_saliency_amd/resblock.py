@@ -1,0 +1,157 @@
+"""A ResNet BasicBlock as ONE autograd node on the HIP kernels.
+
+    out = relu( bn2(conv2( relu(bn1(conv1(x))) )) + skip ),   skip = x  |  bn_d(conv_d(x))
+    (reference block: Classification/models/ResNet.py:93-125)
+
+Forward is 2-3 MFMA convolutions + 2-3 fused BN launches; backward walks the same chain by hand:
+the residual branch's gradient is folded into conv1's backward-data epilogue (`addend`) instead of a separate
+add pass over the activation, and all weight / BN gradients are accumulated by their kernels directly into the
+parameters' `.grad` storage (gradsink.py) — no AccumulateGrad launches.  Per block that removes one
+3-pass elementwise add over the block input and 6-9 small adds, plus the autograd bookkeeping of ~10 nodes.
+
+`fused_basic_block(blk, x)` returns None when the block cannot take this path (non-fp32 / CPU tensors, autocast,
+SyncBatchNorm, shapes outside the convolution kernels' tiling domain — probed once per input shape); the module
+then runs its ordinary forward.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import gradsink, ops
+
+
+def _bn_args(bn: nn.BatchNorm2d):
+    return bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps
+
+
+class _BasicBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, blk, w1, g1, b1, w2, g2, b2, wd, gd, bd):
+        s = blk.conv1.stride[0]
+        N, C, H, W = x.shape
+        P, Q = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+        training = blk.bn1.training
+        c1 = ops.conv2d_forward(x, w1, None, s, 1, P, Q)
+        y1, m1, i1 = ops.bn_forward(c1, None, g1, b1, *_bn_args(blk.bn1), True)
+        c2 = ops.conv2d_forward(y1, w2, None, 1, 1, P, Q)
+        cd = md = idd = None
+        if wd is not None:
+            cd = ops.conv2d_forward(x, wd, None, s, 0, P, Q)
+            skip, md, idd = ops.bn_forward(cd, None, gd, bd, *_bn_args(blk.downsample[1]), False)
+        else:
+            skip = x
+        out, m2, i2 = ops.bn_forward(c2, skip, g2, b2, *_bn_args(blk.bn2), True)
+        if training:
+            blk.bn1.num_batches_tracked.add_(1)
+            blk.bn2.num_batches_tracked.add_(1)
+            if wd is not None:
+                blk.downsample[1].num_batches_tracked.add_(1)
+        ctx.save_for_backward(x, c1, y1, c2, out, cd, w1, g1, b1, w2, g2, b2, wd, gd, bd, m1, i1, m2, i2, md, idd)
+        ctx.cfg = (s, training)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, c1, y1, c2, out, cd, w1, g1, b1, w2, g2, b2, wd, gd, bd, m1, i1, m2, i2, md, idd = ctx.saved_tensors
+        s, training = ctx.cfg
+        dout = dout.contiguous()
+        grads = {}
+
+        def bn_bwd(dy, y, xin, g, b, m, i, relu, want_dres):
+            gw, gb = gradsink.sink(g), gradsink.sink(b)
+            if gw is None or gb is None:
+                gw = gb = None
+            dx, dres, dg, db = ops.bn_backward(dy, y, xin, g, m, i, training, relu, want_dres, gw, gb)
+            if gw is not None:
+                gradsink.arrived(g)
+                gradsink.arrived(b)
+                dg = db = None
+            return dx, dres, dg, db
+
+        def wgrad(xin, dy, w, stride, pad):
+            dst = gradsink.sink(w)
+            dw = ops.conv2d_backward_weight(xin, dy, w.shape, stride, pad, out=dst, accumulate=True)
+            if dst is not None:
+                gradsink.arrived(w)
+                return None
+            return dw
+
+        # parameters are visited last-to-first so gradient-arrival hooks see the order autograd would produce
+        dc2, dskip, dg2, db2 = bn_bwd(dout, out, c2, g2, b2, m2, i2, True, True)
+        dwd = dgd = dbd = None
+        dxd = dskip
+        if wd is not None:
+            dcd, _, dgd, dbd = bn_bwd(dskip, None, cd, gd, bd, md, idd, False, False)
+            dwd = wgrad(x, dcd, wd, s, 0)
+            dxd = ops.conv2d_backward_data(dcd, wd, x.shape, s, 0) if ctx.needs_input_grad[0] else None
+        dw2 = wgrad(y1, dc2, w2, 1, 1)
+        dy1 = ops.conv2d_backward_data(dc2, w2, y1.shape, 1, 1)
+        dc1, _, dg1, db1 = bn_bwd(dy1, y1, c1, g1, b1, m1, i1, True, False)
+        dw1 = wgrad(x, dc1, w1, s, 1)
+        dx = ops.conv2d_backward_data(dc1, w1, x.shape, s, 1, addend=dxd) if ctx.needs_input_grad[0] else None
+        return dx, None, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd
+
+
+def _probe(blk, shape, device) -> bool:
+    """Can every convolution launch of this block run on the MFMA kernels for this input shape?  One-time dry run
+    on uninitialised buffers (only the return codes matter)."""
+    N, C, H, W = shape
+    s = blk.conv1.stride[0]
+    P, Q = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    K = blk.conv1.out_channels
+    if (P * Q) % 4 or (H * W) % 4:
+        return False
+    e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=device)
+    x, y1, dy = e(N, C, H, W), e(N, K, P, Q), e(N, K, P, Q)
+    convs = [(x, blk.conv1.weight, s, 1), (y1, blk.conv2.weight, 1, 1)]
+    if blk.downsample is not None:
+        convs.append((x, blk.downsample[0].weight, s, 0))
+    for xin, w, st, pad in convs:
+        if ops.conv2d_forward(xin, w, None, st, pad, P, Q) is None:
+            return False
+        if ops.conv2d_backward_data(dy, w, xin.shape, st, pad, addend=xin) is None:
+            return False
+        if ops.conv2d_backward_weight(xin, dy, w.shape, st, pad) is None:
+            return False
+    return True
+
+
+def _structure_ok(blk) -> bool:
+    convs = [blk.conv1, blk.conv2] + ([blk.downsample[0]] if blk.downsample is not None else [])
+    bns = [blk.bn1, blk.bn2] + ([blk.downsample[1]] if blk.downsample is not None else [])
+    if any(type(b) is not nn.BatchNorm2d or not b.affine or not b.track_running_stats or b.momentum is None
+           for b in bns):
+        return False
+    if any(c.bias is not None or c.groups != 1 or c.dilation != (1, 1) or c.weight.dtype != torch.float32
+           for c in convs):
+        return False
+    if len({b.training for b in bns}) != 1:
+        return False
+    c1, c2 = blk.conv1, blk.conv2
+    ok = (c1.kernel_size == (3, 3) and c1.padding == (1, 1) and c1.stride[0] == c1.stride[1] and c1.stride[0] in (1, 2)
+          and c2.kernel_size == (3, 3) and c2.padding == (1, 1) and c2.stride == (1, 1))
+    if blk.downsample is not None:
+        d = blk.downsample[0]
+        ok = ok and d.kernel_size == (1, 1) and d.padding == (0, 0) and d.stride == c1.stride
+    else:
+        ok = ok and c1.stride == (1, 1) and c1.in_channels == c1.out_channels
+    return ok
+
+
+def fused_basic_block(blk, x: torch.Tensor):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) or torch.is_autocast_enabled():
+        return None
+    cache = blk.__dict__.setdefault("_fused_shapes", {})
+    key = (tuple(x.shape), x.device)
+    ok = cache.get(key)
+    if ok is None:
+        with torch.no_grad():
+            ok = cache[key] = _structure_ok(blk) and _probe(blk, tuple(x.shape), x.device)
+    if not ok or not _structure_ok(blk):
+        return None
+    x = x.contiguous()
+    d = blk.downsample
+    return _BasicBlockFn.apply(x, blk, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight,
+                               blk.bn2.weight, blk.bn2.bias, d[0].weight if d is not None else None,
+                               d[1].weight if d is not None else None, d[1].bias if d is not None else None)

@@ -490,9 +490,21 @@ __global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward-weight.  Workgroup: 4 waves = 2 k-tiles x 2 c-tiles of 32; each wave keeps RS accumulators.
+// backward-weight.  Workgroup: 4 waves = 2 k-tiles x 2 c-tiles of 32; each wave keeps RS accumulators (one per
+// filter tap), so a 64-pixel chunk of x / dy staged in LDS feeds R*R MFMAs per pixel pair.
 // grid = (K/64 rounded up, C/64 rounded up, nsplit); split s handles pixel chunks s, s+nsplit, ...
-template <int R, int STRIDE>
+//
+// The kernel runs ONE wave per SIMD (9 x 16 accumulator registers), so nothing hides instruction issue: whenever
+// the wave is busy issuing loads / LDS traffic / address arithmetic, its matrix pipe drains (measured: a staging
+// phase between MFMA groups costs 25-45 % — tools/micro/mfma_peak.hip has the ceilings).  Hence:
+//   * everything that is not an MFMA is cut into slots of a few instructions and pinned (sched_barrier) BETWEEN
+//     consecutive MFMAs, each of which keeps the pipe busy for 64 cycles;
+//   * slots are branch free (one basic block per pixel pair): loads use clamped addresses + an AND mask instead of
+//     predication, LDS stores of idle lanes go to a dump row;
+//   * chunk i+1 travels global -> registers during the first half of chunk i's pixel pairs and registers -> the
+//     OTHER LDS buffer during the second half; one barrier per chunk;
+//   * x addresses are scalar base (image, channel) + one per-lane offset, so a load costs no vector ALU.
+template <int R, int STRIDE, bool FULLC>
 __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, const float *__restrict__ dy,
                                                   float *__restrict__ part, int N, int C, int H, int W, int K, int P,
                                                   int Q, int pad, int NI, int TP, int IH_t, int IW_t, int logQ,
@@ -500,11 +512,16 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
   constexpr int RS = R * R;
   constexpr int PIXC = (STRIDE == 1) ? 64 : 32;  // pixels per chunk (stride 2: 32, so the patch stays <= 256 floats)
   constexpr int DROW = PIXC + 1;
+  constexpr int NSTEP = PIXC / 2;                // pixel pairs per chunk
+  constexpr int HALF = NSTEP / 2;
+  constexpr int CPS = 64 / HALF;                 // x channels staged per pixel-pair step (4 or 8)
+  constexpr int DN4 = 64 * PIXC / 4 / 256;       // float4 items of dy per thread and chunk (4 or 2)
+  static_assert(DN4 * 4 == HALF, "one dy scalar is stored per step of the second half");
+  constexpr int LOGPIX4 = (PIXC == 64) ? 4 : 3;  // log2(PIXC / 4)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int PSZ = NI * IH_t * IW_t;
   const int ch_stride = PSZ | 1;
-  float *xp = lds;                    // [64 c][ch_stride]
-  float *dl = lds + 64 * ch_stride;   // [64 k][DROW]
+  const int BUF = 64 * ch_stride + 64 * DROW + 256;  // floats per LDS buffer: xp[64 c][ch_stride] + dl[64 k][DROW] + dump
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 31, hi = lane >> 5;
@@ -513,6 +530,8 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
   const int split = blockIdx.z, nsplit = gridDim.z;
   const int tiles_per_img = (NI > 1) ? 1 : P / TP;
   const int planeHW = H * W, PQ = P * Q;
+  const int logTP = __builtin_ctz(TP);
+  const int cmax = C - c0;  // channels c < cmax of this tile are real (>= 64 when FULLC)
 
   f32x16 acc[RS];
 #pragma unroll
@@ -520,98 +539,151 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
-  // Register-staged software pipeline (as in conv_igemm): chunk i+1 is fetched from global memory while the
-  // matrix cores work on chunk i.
-  // one patch position per thread (PSZ <= 256 by construction of PIXC): 64 channel values + the dy slice
+  // ---- staging state: one patch position per thread (PSZ <= 256) x 64 channels, and DN4 float4 of dy
   float xreg[64];
-  constexpr int DN = 64 * PIXC / 256;
-  float dreg[DN];
-  constexpr int LOGPIX = (PIXC == 64) ? 6 : 5;
-
-  auto load_chunk = [&](int chunk) {
+  float4 dreg[DN4];
+  const float *xbase = x;      // uniform: &x[n0][c0][0][0] of the chunk being fetched
+  unsigned xoff = 0;           // per lane: float offset of the patch position inside that image block (0 if masked)
+  unsigned xmask = 0;          // per lane: ~0 if the position is inside the image, 0 for padding / idle lanes
+  const float *dbase = dy;     // uniform: &dy[n0][k0][p0][0]
+  unsigned doff[DN4], dmask[DN4];
+  // patch position of this thread (chunk independent)
+  const int e_ni = tid / (IH_t * IW_t);
+  const int e_rem = tid - e_ni * (IH_t * IW_t);
+  const int e_ih = e_rem / IW_t, e_iw = e_rem - e_ih * IW_t;
+  const int ww = -pad + e_iw;
+  const bool e_ok = tid < PSZ && ww >= 0 && ww < W;
+  // LDS store addressing: idle lanes (tid >= PSZ) write every channel to their own dump slot
+  const int st_base = tid < PSZ ? tid : 64 * ch_stride + 64 * DROW + tid;
+  const int st_cmul = tid < PSZ ? ch_stride : 0;
+  // dy float4 items of this thread (chunk independent part)
+  int d_kk[DN4], d_ni[DN4], d_in[DN4];
+#pragma unroll
+  for (int i = 0; i < DN4; ++i) {
+    const int e4 = tid + i * 256;
+    const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4;
+    const int q = m & (Q - 1), pr = m >> logQ;
+    d_kk[i] = kk;
+    d_ni[i] = pr >> logTP;
+    d_in[i] = (pr & (TP - 1)) * Q + q;
+  }
+  auto aim = [&](int chunk) {  // source addresses for `chunk`
     int n0, p0;
     if (NI > 1) { n0 = chunk * NI; p0 = 0; }
     else { n0 = chunk / tiles_per_img; p0 = (chunk - n0 * tiles_per_img) * TP; }
-    {
-      const int e = tid;
-      const int ni = e / (IH_t * IW_t);
-      const int rem = e - ni * (IH_t * IW_t);
-      const int ih = rem / IW_t, iw = rem - ih * IW_t;
-      const int n = n0 + ni;
-      const int h = p0 * STRIDE - pad + ih, ww = -pad + iw;
-      const bool ok = (e < PSZ) && (n < N) && h >= 0 && h < H && ww >= 0 && ww < W;
-      const float *src = x + (ok ? ((size_t)n * C * planeHW + (size_t)h * W + ww + (size_t)c0 * planeHW) : 0);
-      const int cvalid = ok ? (C - c0) : 0;  // channels c < cvalid are real
+    const int n = n0 + e_ni;
+    const int h = p0 * STRIDE - pad + e_ih;
+    const bool ok = e_ok && (n < N) && h >= 0 && h < H;
+    xbase = x + ((size_t)n0 * C + c0) * planeHW;
+    xoff = ok ? (unsigned)((e_ni * C) * planeHW + h * W + ww) : 0u;
+    xmask = ok ? 0xffffffffu : 0u;
+    dbase = dy + ((size_t)n0 * K + k0) * PQ + (size_t)p0 * Q;
 #pragma unroll
-      for (int c = 0; c < 64; ++c) {
-        const bool okc = c < cvalid;
-        const float t = src[okc ? (size_t)c * planeHW : 0];  // clamped address, unconditional load
-        xreg[c] = okc ? t : 0.f;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < DN; ++i) {
-      const int e = tid + i * 256;
-      const int kk = e >> LOGPIX, m = e & (PIXC - 1);
-      const int q = m & (Q - 1), pr = m >> logQ;
-      const int ni = pr / TP, pl = pr - ni * TP;
-      const int n = n0 + ni;
-      const bool okd = n < N && (k0 + kk) < K;
-      const float t = dy[okd ? (((size_t)n * K + (k0 + kk)) * PQ + (size_t)(p0 + pl) * Q + q) : 0];
-      dreg[i] = okd ? t : 0.f;
+    for (int i = 0; i < DN4; ++i) {
+      const bool okd = (n0 + d_ni[i]) < N && (k0 + d_kk[i]) < K;
+      doff[i] = okd ? (unsigned)((d_ni[i] * K + d_kk[i]) * PQ + d_in[i]) : 0u;
+      dmask[i] = okd ? 0xffffffffu : 0u;
     }
   };
-  auto store_chunk = [&]() {
-    if (tid < PSZ) {
-#pragma unroll
-      for (int c = 0; c < 64; ++c) xp[c * ch_stride + tid] = xreg[c];
-    }
-#pragma unroll
-    for (int i = 0; i < DN; ++i) {
-      const int e = tid + i * 256;
-      dl[(e >> LOGPIX) * DROW + (e & (PIXC - 1))] = dreg[i];
-    }
+  // loads: unconditional, from a clamped (always valid) address; the value is masked when it is STORED to LDS half a
+  // chunk later, so that nothing in a load slot depends on the load's result (no wait for memory between MFMAs)
+  auto load_x = [&](int c) {
+    const int cc = FULLC ? c : (c < cmax ? c : cmax - 1);
+    xreg[c] = (xbase + (size_t)cc * planeHW)[xoff];
+  };
+  auto load_d = [&](int i) { dreg[i] = *reinterpret_cast<const float4 *>(dbase + doff[i]); };
+  auto store_x = [&](float *buf, int c) {
+    const unsigned m = FULLC ? xmask : (c < cmax ? xmask : 0u);
+    buf[st_base + c * st_cmul] = __uint_as_float(__float_as_uint(xreg[c]) & m);
+  };
+  auto store_d = [&](float *dl, int sidx) {  // scalar #sidx (0 .. 4*DN4-1) of this thread's dy items
+    const int i = sidx >> 2, comp = sidx & 3;
+    const int e4 = tid + i * 256;
+    const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4 + comp;
+    const float v = comp == 0 ? dreg[i].x : comp == 1 ? dreg[i].y : comp == 2 ? dreg[i].z : dreg[i].w;
+    dl[kk * DROW + m] = __uint_as_float(__float_as_uint(v) & dmask[i]);
   };
 
-  // spatial offset of pixel m of the chunk inside one channel's patch (same for every chunk): a 64-entry table
-  // instead of a shift/divide chain per pixel pair in the MFMA loop
-  int *soff = reinterpret_cast<int *>(dl + 64 * DROW);  // carved from the dynamic LDS block (PIXC ints)
-  if (tid < PIXC) {
-    const int q = tid & (Q - 1), pr = tid >> logQ;
-    const int ni = pr / TP, pl = pr - ni * TP;
-    soff[tid] = (ni * IH_t + pl * STRIDE) * IW_t + q * STRIDE;
-  }
-  if (split < nchunks) load_chunk(split);
-  const float *arow = dl + (kt * 32 + lo) * DROW;
-  const float *brow = xp + (ct * 32 + lo) * ch_stride;
-  for (int chunk = split; chunk < nchunks; chunk += nsplit) {
+  if (split < nchunks) {
+    // prologue: chunk `split` into buffer 0
+    aim(split);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) load_x(c);
+#pragma unroll
+    for (int i = 0; i < DN4; ++i) load_d(i);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) store_x(lds, c);
+#pragma unroll
+    for (int sidx = 0; sidx < 4 * DN4; ++sidx) store_d(lds + 64 * ch_stride, sidx);
     __syncthreads();
-    store_chunk();
-    __syncthreads();
-    if (chunk + nsplit < nchunks) load_chunk(chunk + nsplit);
-    // one-step-ahead operand pipeline: the 1 + R*R LDS operands of pixel pair i+1 are read while the R*R MFMAs
-    // of pair i run
-    auto operands = [&](int j, float &av, float (&bv)[RS]) {
-      const int m = j + hi;
-      av = arow[m];
-      const float *bp = brow + soff[m];
+
+    int cur = 0;
+    for (int chunk = split; chunk < nchunks; chunk += nsplit) {
+      const float *xp = lds + cur * BUF;
+      const float *dl = xp + 64 * ch_stride;
+      float *xp_n = lds + (cur ^ 1) * BUF;
+      float *dl_n = xp_n + 64 * ch_stride;
+      // the last chunk of this split re-stages itself (harmless) so that the loop body is branch free
+      aim(chunk + nsplit < nchunks ? chunk + nsplit : chunk);
+      const float *arow = dl + (kt * 32 + lo) * DROW + hi;
+      const float *brow = xp + (ct * 32 + lo) * ch_stride + hi * STRIDE;
+      // operands of pixel pair j: A = dy[k][j + hi], B = the R*R taps of x at that pixel.  The pair's patch offset
+      // is wave-uniform: q = (j & (Q-1)) + hi (j even, Q >= 4), both lane halves in the same row.
+      auto pair_off = [&](int j) {
+        const int q0 = j & (Q - 1), pr = j >> logQ;
+        const int ni = pr >> logTP, pl = pr & (TP - 1);
+        return (ni * IH_t + pl * STRIDE) * IW_t + q0 * STRIDE;
+      };
+      float a_cur, b_cur[RS], a_nxt = 0.f, b_nxt[RS];
+      {
+        const float *bp = brow + pair_off(0);
+        a_cur = arow[0];
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+        for (int t = 0; t < RS; ++t) b_cur[t] = bp[(t / R) * IW_t + (t % R)];
+      }
 #pragma unroll
-        for (int s2 = 0; s2 < R; ++s2) bv[r * R + s2] = bp[r * IW_t + s2];
-    };
-    float a_cur, b_cur[RS], a_nxt = 0.f, b_nxt[RS];
-    operands(0, a_cur, b_cur);
+      for (int st = 0; st < NSTEP; ++st) {
+        const float *bp = brow + ((st + 1 < NSTEP) ? pair_off(2 * st + 2) : 0);
 #pragma unroll
-    for (int j = 0; j < PIXC; j += 2) {
-      if (j + 2 < PIXC) operands(j + 2, a_nxt, b_nxt);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < RS; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- slot t: a few non-MFMA instructions in the shadow of the MFMA just issued
+          if (st + 1 < NSTEP) {
+            if (t == 0) a_nxt = arow[2 * st + 2];
+            b_nxt[t] = bp[(t / R) * IW_t + (t % R)];
+          }
+          // staging work of this step, spread over the slots (CPS items + 1 dy item per step)
+          constexpr int SPREAD = (RS >= 9) ? ((CPS == 4) ? 2 : 1) : 0;  // slot distance between staging items
+          if (RS >= 9) {
+            if (st < HALF) {
+              if (CPS == 4 ? ((t & 1) == 1 && t / 2 < CPS) : (t < CPS)) load_x(st * CPS + (CPS == 4 ? t / 2 : t));
+              if (t == RS - 1 && st < DN4) load_d(st);
+            } else {
+              if (CPS == 4 ? ((t & 1) == 1 && t / 2 < CPS) : (t < CPS))
+                store_x(xp_n, (st - HALF) * CPS + (CPS == 4 ? t / 2 : t));
+              if (t == RS - 1) store_d(dl_n, st - HALF);
+            }
+          } else if (t == RS - 1) {  // few MFMAs per step (1x1 filters): all staging items in the last slot
+            if (st < HALF) {
 #pragma unroll
-      for (int t = 0; t < RS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a_cur = a_nxt;
+              for (int cc = 0; cc < CPS; ++cc) load_x(st * CPS + cc);
+              if (st < DN4) load_d(st);
+            } else {
 #pragma unroll
-      for (int t = 0; t < RS; ++t) b_cur[t] = b_nxt[t];
+              for (int cc = 0; cc < CPS; ++cc) store_x(xp_n, (st - HALF) * CPS + cc);
+              store_d(dl_n, st - HALF);
+            }
+          }
+          (void)SPREAD;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        a_cur = a_nxt;
+#pragma unroll
+        for (int t = 0; t < RS; ++t) b_cur[t] = b_nxt[t];
+      }
+      __syncthreads();
+      cur ^= 1;
     }
   }
   // ---- partial[split][rs][k][c]: a wave's 32 result columns (c) are contiguous => coalesced 128-B stores;
@@ -856,7 +928,9 @@ int launch_dgrad(const float *dy, const float *w, const float *addend, float *dx
 
 inline int wgrad_nsplit(int K, int C, int nchunks) {
   const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
-  int ns = (768 + tiles - 1) / tiles;
+  // one workgroup per CU is resident (register budget): a single full round of 256 workgroups, each with a long
+  // run of chunks, beats more and shorter splits (prologue/epilogue and partial-sum traffic scale with nsplit)
+  int ns = (256 + tiles - 1) / tiles;
   if (ns > nchunks) ns = nchunks;
   if (ns < 1) ns = 1;
   return ns;
@@ -921,18 +995,27 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
   if (ws_bytes < need) return SALUN_ENOSPC;
   hipStream_t st = salun_hip_stream(stream);
   const int PSZ = g.NI * g.IH_t * g.IW_t;
-  const size_t ldsb = sizeof(float) * ((size_t)64 * (PSZ | 1) + (size_t)64 * (pixc + 1) + (size_t)pixc);
+  if (Q < 4 || (g.TP & (g.TP - 1)) != 0) return SALUN_EINVAL;  // float4 dy staging; shift-only pixel decoding
+  const size_t ldsb = sizeof(float) * 2 * ((size_t)64 * (PSZ | 1) + (size_t)64 * (pixc + 1) + 256);  // double buffered
+  // per-lane offsets inside one chunk's image block are 32-bit
+  if ((size_t)g.NI * C * H * W >= (1u << 30) || (size_t)g.NI * K * P * Q >= (1u << 30)) return SALUN_EINVAL;
   if (ldsb > 160 * 1024) return SALUN_EINVAL;
   dim3 grid((K + 63) / 64, (C + 63) / 64, ns);
   float *part = static_cast<float *>(ws);
 #define SALUN_WGRAD(R_, S_)                                                                                    \
-  allow_lds(conv_wgrad<R_, S_>, ldsb);                                                                         \
-  hipLaunchKernelGGL((conv_wgrad<R_, S_>), grid, dim3(256), ldsb, st, x, dy, part, N, C, H, W, K, P, Q, pad,   \
-                     g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles)
-  if (R == 3 && stride == 1) { SALUN_WGRAD(3, 1); }
-  else if (R == 3 && stride == 2) { SALUN_WGRAD(3, 2); }
-  else if (R == 1 && stride == 1) { SALUN_WGRAD(1, 1); }
-  else { SALUN_WGRAD(1, 2); }
+  if (C % 64 == 0) {                                                                                           \
+    allow_lds(conv_wgrad<R_, S_, true>, ldsb);                                                                 \
+    hipLaunchKernelGGL((conv_wgrad<R_, S_, true>), grid, dim3(256), ldsb, st, x, dy, part, N, C, H, W, K, P,   \
+                       Q, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles);                                  \
+  } else {                                                                                                     \
+    allow_lds(conv_wgrad<R_, S_, false>, ldsb);                                                                \
+    hipLaunchKernelGGL((conv_wgrad<R_, S_, false>), grid, dim3(256), ldsb, st, x, dy, part, N, C, H, W, K, P,  \
+                       Q, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles);                                  \
+  }
+  if (R == 3 && stride == 1) { SALUN_WGRAD(3, 1) }
+  else if (R == 3 && stride == 2) { SALUN_WGRAD(3, 2) }
+  else if (R == 1 && stride == 1) { SALUN_WGRAD(1, 1) }
+  else { SALUN_WGRAD(1, 2) }
 #undef SALUN_WGRAD
   SALUN_LAUNCH_CHECK();
   const int64_t n = (int64_t)K * C * R * R;

@@ -87,8 +87,9 @@ int salun_mask_topk(const float *acc /*dev*/, int64_t n, const int64_t *ks /*hos
                     int nk, uint8_t *const *masks_out /*host array of dev ptrs*/,
                     void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 /* After salun_mask_topk on the same ws: copies the nk selected thresholds
- * (as fp32 |acc| values; NaN if the k-th element is a NaN) to a host-visible
- * device array — diagnostic only, 4*nk bytes. */
+ * (as fp32 |acc| values; NaN if the k-th element is a NaN; +inf for k <= 0, -1 for
+ * k > n) to a device array, 4*nk bytes.  Used by the proximal step (K9) as the
+ * device-resident threshold. */
 int salun_mask_topk_thresholds(const void *ws /*dev*/, int nk, float *tau_out /*dev*/,
                                salun_stream_t stream);
 
@@ -239,6 +240,31 @@ int salun_bn_backward(const float *dy /*dev*/, const float *y /*dev, needed if r
                       float *grad_gamma_acc /*dev or NULL: += dgamma*/, float *grad_beta_acc /*dev or NULL: += dbeta*/,
                       int N, int C, int HW, int training, int relu, void *ws /*dev*/, size_t ws_bytes,
                       salun_stream_t stream);
+
+/* ------------------------------------------------------------------ K9 --
+ * Proximal (soft-threshold) step of RL_proximal — Classification/unlearn/RL_pro.py:52-60:
+ *     d = params - init_params ; threshold = -topk(-|d|, ratio)[0][-1] ;
+ *     params = where(d > thr, params - thr, where(d < -thr, params + thr, init_params))
+ * as three launches on the flat vectors:  salun_param_diff (out = p - p0, 12 B/elem)  ->  salun_mask_topk on `out`
+ * with k = n - ratio + 1 (its k-th largest |d| IS the ratio-th smallest; threshold fetched on the device with
+ * salun_mask_topk_thresholds)  ->  salun_soft_threshold_step (12 B/elem), which reads the threshold from device
+ * memory — no host round trip.  fp32 arithmetic identical to the reference's tensor expressions. */
+int salun_param_diff(const float *p /*dev*/, const float *p0 /*dev*/, float *out /*dev*/, int64_t n,
+                     salun_stream_t stream);
+int salun_soft_threshold_step(float *p /*dev*/, const float *p0 /*dev*/, const float *tau /*dev, 1 float*/,
+                              int64_t n, salun_stream_t stream);
+
+/* ----------------------------------------------------------------- K10 --
+ * EWC (Selective-Amnesia) penalty of DDPM train_forget — DDPM/runners/diffusion.py:343-350:
+ *     loss += lambda * sum_name sum( fisher[name] * (param - params_mle[name])**2 )
+ * One launch over the flat vectors instead of 334 x 4 per-tensor ops + autograd:
+ *     g += (lambda*F) * (2*(p - p_star))      (the term's autograd gradient, fp32)
+ *     loss_out[0] = lambda * S, loss_out[1] = S = sum F (p - p_star)^2   (fp64 partials, fixed order)
+ * Algorithmic traffic: 20 B / element (r p, p_star, F, g; w g).  Workspace: salun_ewc_workspace_bytes(n). */
+size_t salun_ewc_workspace_bytes(int64_t n);
+int salun_ewc_penalty_grad(const float *p /*dev*/, const float *p_star /*dev*/, const float *F /*dev*/,
+                           float *g /*dev*/, double lambda, float *loss_out /*dev, 2 floats*/, int64_t n,
+                           void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 
 /* ------------------------------------------------------------------ K0 --
  * Device-resident CIFAR batch assembly (replaces the host DataLoader path

@@ -194,3 +194,32 @@ def fill_u8(n: int, seed: int) -> np.ndarray:
     out = np.empty(n, np.uint8)
     lib().oracle_fill_u8(_p(out, _u8p), ctypes.c_int64(n), ctypes.c_uint64(seed))
     return out
+
+
+# ------------------------------------------------------------------ next rows, numpy
+def proximal_threshold(p: np.ndarray, p0: np.ndarray, ratio: int) -> np.float32:
+    """threshold = -torch.topk(-|p - p0|, ratio)[0][-1]  — the ratio-th smallest |p - p0|
+    (Classification/unlearn/RL_pro.py:53-56).  ratio < 1 raises like the reference's [-1] on an empty result."""
+    if ratio < 1:
+        raise IndexError("index -1 is out of bounds for dimension 0 with size 0")
+    d = np.abs(_f32(p) - _f32(p0))
+    return np.partition(d, ratio - 1)[ratio - 1]
+
+
+def soft_threshold_step(p: np.ndarray, p0: np.ndarray, ratio: int) -> np.float32:
+    """In place: params = where(d > thr, params - thr, where(d < -thr, params + thr, init_params))
+    (RL_pro.py:56-58), all fp32.  Returns the threshold."""
+    thr = np.float32(proximal_threshold(p, p0, ratio))
+    d = _f32(p) - _f32(p0)
+    p[...] = np.where(d > thr, p - thr, np.where(d < -thr, p + thr, p0)).astype(np.float32)
+    return thr
+
+
+def ewc_penalty_grad(p, p_star, F, g, lam: float):
+    """EWC term of DDPM train_forget (DDPM/runners/diffusion.py:343-350): returns lam * sum F (p - p*)^2 (fp64
+    accumulation of fp32 products) and adds its autograd gradient (lam*F) * (2*(p - p*)) to g in place, fp32."""
+    lam32 = np.float32(lam)
+    d = _f32(p) - _f32(p_star)
+    s = float(np.sum((_f32(F) * (d * d)).astype(np.float64)))
+    g += (lam32 * _f32(F)) * (np.float32(2.0) * d)
+    return float(lam32) * s, s

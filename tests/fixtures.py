@@ -128,3 +128,30 @@ def sd_tiny_config():
     return dict(image_size=8, in_channels=4, out_channels=4, model_channels=32, attention_resolutions=(2, 1),
                 num_res_blocks=1, channel_mult=(1, 2), num_heads=4, use_spatial_transformer=True, transformer_depth=1,
                 context_dim=24, use_checkpoint=False, legacy=False)
+
+
+# ------------------------------------------------------------------ "next rows" fixtures
+def next_rows_datasets():
+    """24 forget + 40 retain uint8 8x8 images as ArrayDatasets (test transform: no augmentation randomness)."""
+    from unlearn_saliency_amd.Classification.dataset import ArrayDataset
+    fx = rng.u8(24 * 8 * 8 * 3, 1100).reshape(24, 8, 8, 3)
+    fy = (rng.u8(24, 1101) % 10).astype(np.int64)
+    rx = rng.u8(40 * 8 * 8 * 3, 1102).reshape(40, 8, 8, 3)
+    ry = (rng.u8(40, 1103) % 10).astype(np.int64)
+    return ArrayDataset(fx, fy, transform="test"), ArrayDataset(rx, ry, transform="test")
+
+
+def ewc_inputs():
+    shapes = [(16, 8, 3, 3), (16,), (32, 16), (32,)]
+    ps, stars, Fs = [], [], []
+    for i, s in enumerate(shapes):
+        k = int(np.prod(s))
+        stars.append(rng.normal(k, 1300 + i, 0.0, 0.05))
+        ps.append((stars[-1] + rng.normal(k, 1310 + i, 0.0, 0.01)).astype(np.float32))
+        Fs.append(np.abs(rng.normal(k, 1320 + i, 0.0, 1.0)).astype(np.float32))
+    return np.concatenate(ps), np.concatenate(stars), np.concatenate(Fs)
+
+
+def fisher_fixture(shapes):
+    """Per-parameter Fisher tensors U[0, 50) from the counter-based generator (SURVEY.md §8 F3 fixtures)."""
+    return [rng.uniform(int(np.prod(s)), 9000 + 17 * i, 0.0, 50.0).reshape(s) for i, s in enumerate(shapes)]

@@ -148,6 +148,35 @@ def test_saliency_unlearn_matches_reference(golden_dir, workdir, method):
     assert np.allclose(sums, g["tensor_sums"], rtol=1e-4, atol=3e-3)
 
 
+def test_train_forget_matches_reference(golden_dir, workdir):
+    """`Diffusion.train_forget` (EWC anchor on the fused penalty kernel) vs the reference's loop with
+    every random draw replayed; the Fisher dictionary travels in the reference's pickle format."""
+    import pickle
+    from fixtures import fisher_fixture
+    from unlearn_saliency_amd.DDPM.models.diffusion import Conditional_Model
+    from unlearn_saliency_amd.DDPM.runners import diffusion as RD
+    g = np.load(os.path.join(golden_dir, "ddpm_train_forget.npz"))
+    cfg = ddpm_small_config()
+    cfg.training.n_iters = int(g["n_iters"])
+    cfg.training.gamma, cfg.training.lmbda = int(g["gamma"]), int(g["lmbda"])
+    cfg.ckpt_dir = os.path.join(workdir, "out")
+    os.makedirs(cfg.ckpt_dir)
+    ref_model = Conditional_Model(cfg)
+    F = fisher_fixture([tuple(p.shape) for p in ref_model.parameters()])
+    with open(os.path.join(workdir, "fisher_dict.pkl"), "wb") as f:
+        pickle.dump({"module." + n: torch.from_numpy(a) for (n, _), a in zip(ref_model.named_parameters(), F)}, f)
+    runner = RD.Diffusion(_args(workdir), cfg)
+    with R.replay(randn=g["randn"], randint=g["randint"], rand=g["rand"]):
+        model = runner.train_forget(remember_loader=_batches(300))
+    lr = cfg.optim.lr
+    got, ref = flat_params(model)[::STRIDE], g["param_sample"]
+    close = np.abs(got - ref) <= 0.02 * lr + 1e-6 * np.abs(ref)
+    assert close.mean() > 0.99, close.mean()
+    assert np.abs(got - ref).max() <= 6 * lr
+    sums = np.array([float(p.detach().double().sum()) for p in model.parameters()])
+    assert np.allclose(sums, g["tensor_sums"], rtol=1e-4, atol=3e-3)
+
+
 def test_save_fim_matches_reference(golden_dir, workdir):
     from unlearn_saliency_amd.DDPM.runners.diffusion import Diffusion
     g = np.load(os.path.join(golden_dir, "ddpm_fim.npz"))

@@ -129,6 +129,27 @@ def test_saliency_unlearn_restatement_vs_reference(oracle_mod, golden_dir, metho
     assert np.allclose(sums, g["tensor_sums"], rtol=1e-4, atol=2e-3)
 
 
+def test_train_forget_restatement_vs_reference(oracle_mod, golden_dir):
+    """EWC / Selective-Amnesia loop: 3 iterations, the fused EWC term entering before the clip."""
+    from fixtures import fisher_fixture
+    from unlearn_saliency_amd.DDPM.models.diffusion import Conditional_Model
+    g = np.load(os.path.join(golden_dir, "ddpm_train_forget.npz"))
+    cfg = ddpm_small_config()
+    cfg.training.gamma, cfg.training.lmbda = int(g["gamma"]), int(g["lmbda"])
+    model = fill_params(Conditional_Model(cfg), 7000)
+    F = np.concatenate([a.reshape(-1) for a in fisher_fixture([tuple(p.shape) for p in model.parameters()])])
+    with R.replay(randn=g["randn"], randint=g["randint"], rand=g["rand"]):
+        losses = R.cpu_train_forget(cfg, model, _batches(300), F, n_iters=int(g["n_iters"]))
+    assert losses[0][1] == 0.0 and losses[2][1] > 0.0  # theta == theta* at the first step, then the anchor pulls
+    lr = cfg.optim.lr
+    got, ref = flat_params(model)[::STRIDE], g["param_sample"]
+    close = np.abs(got - ref) <= 0.02 * lr + 1e-6 * np.abs(ref)
+    assert close.mean() > 0.995, close.mean()
+    assert np.abs(got - ref).max() <= 3 * lr * 2
+    sums = np.array([float(p.detach().double().sum()) for p in model.parameters()])
+    assert np.allclose(sums, g["tensor_sums"], rtol=1e-4, atol=2e-3)
+
+
 def test_fim_restatement_vs_reference(oracle_mod, golden_dir):
     from unlearn_saliency_amd.DDPM.models.diffusion import Conditional_Model
     g = np.load(os.path.join(golden_dir, "ddpm_fim.npz"))

@@ -58,6 +58,9 @@ _REFERENCE_FLAGS = [
     ("--indexes_to_replace", dict(type=list, default=None, help="Specific index data to forget")),
     ("--alpha", dict(type=float, default=0.2, help="unlearn noise")),
     ("--mask_path", dict(type=str, default=None, help="the path of saliency map")),
+    ("--mask_ratio", dict(type=float, default=None,
+                          help="RL_proximal: fraction of weights reset per step at the start of the schedule "
+                               "(read as args.mask_ratio by the reference's RL_pro.py:13, which never defines the flag)")),
 ]
 
 # Extensions of the MI355X build.

@@ -4,14 +4,17 @@
 ``method(data_loaders, model, criterion, args, mask=None) -> None`` that mutates `model`
 in place; unknown names raise NotImplementedError exactly like the reference.  All 17
 registry names are kept so command lines stay drop-in; the SalUn hot path (RL with a
-mask) and the baselines that share its fused step (GA, GA_l1, FT, FT_l1, raw) are
-implemented, the remaining baselines are registered but raise with a scope note
-(they are the "next" rows, not part of the accelerated path).
+mask), the baselines that share its fused step (GA, GA_l1, FT, FT_l1, raw, boundary_shrink,
+boundary_expanding — SURVEY.md §8 F1) and the proximal variant (RL_proximal, F2) are
+implemented; the Fisher / pruning / retrain baselines are registered but raise with a scope note.
 """
+from .boundary_ex import boundary_expanding
+from .boundary_sh import boundary_shrink
 from .FT import FT, FT_l1
 from .GA import GA, GA_l1
 from .impl import (FusedMaskedSGD, iterative_unlearn, load_unlearn_checkpoint, save_unlearn_checkpoint)
 from .RL import RL
+from .RL_pro import RL_proximal
 
 
 def raw(data_loaders, model, criterion, args, mask=None):
@@ -37,9 +40,7 @@ _REGISTRY = {
     "FT_prune_bi": _out_of_scope("FT_prune_bi", "pruning baseline"),
     "GA_prune": _out_of_scope("GA_prune", "pruning baseline"),
     "GA_prune_bi": _out_of_scope("GA_prune_bi", "pruning baseline"),
-    "boundary_expanding": _out_of_scope("boundary_expanding", "boundary-unlearning baseline, F1 next"),
-    "boundary_shrink": _out_of_scope("boundary_shrink", "boundary-unlearning baseline, F1 next"),
-    "RL_proximal": _out_of_scope("RL_proximal", "proximal variant, F2 next"),
+    "boundary_expanding": boundary_expanding, "boundary_shrink": boundary_shrink, "RL_proximal": RL_proximal,
 }
 
 

@@ -28,13 +28,18 @@ def run_pass(loader, model, criterion, optimizer, epoch: int, args, *,
              label_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
              loss_sign: float = 1.0, l1_alpha: float = 0.0, track: bool = True,
              losses: Optional[utils.AverageMeter] = None, top1: Optional[utils.AverageMeter] = None,
-             loader_len: Optional[int] = None, warmup_steps_per_epoch: Optional[int] = None):
+             loader_len: Optional[int] = None, warmup_steps_per_epoch: Optional[int] = None,
+             batch_label_fn: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None,
+             after_step: Optional[Callable[[int], None]] = None, step_offset: int = 0):
     """Run every batch of `loader` through forward/backward/fused-step.
 
     label_fn   maps the batch's true targets (CPU or device) to the targets used in the loss
                (RL: fresh uniform random labels); None keeps them.
     loss_sign  -1 for gradient ascent.      l1_alpha  weight of the l1 penalty (FT_l1 / GA_l1).
     track      update `losses` / `top1` (sample-weighted) like the reference's retain loop.
+    batch_label_fn  (device image, device true target) -> labels for the loss; accuracy is still measured against
+               the TRUE targets (boundary_sh.py:99-116: loss on the adversarial neighbour label, prec1 on `target`).
+    after_step      called with the loop index after every optimizer step (RL_proximal's soft-threshold).
     """
     dev = next(model.parameters()).device
     loader_len = len(loader) if loader_len is None else loader_len
@@ -50,8 +55,9 @@ def run_pass(loader, model, criterion, optimizer, epoch: int, args, *,
         image = image.to(dev, non_blocking=True)
         target = target.to(dev, non_blocking=True)
 
+        loss_target = target if batch_label_fn is None else batch_label_fn(image, target)
         output = model(image)
-        loss = criterion(output, target)
+        loss = criterion(output, loss_target)
         if loss_sign != 1.0:
             loss = loss_sign * loss
         if l1_alpha:
@@ -60,6 +66,8 @@ def run_pass(loader, model, criterion, optimizer, epoch: int, args, *,
         optimizer.zero_grad()
         loss.backward()
         optimizer.step()
+        if after_step is not None:
+            after_step(i + step_offset)
 
         if track:
             n = image.size(0)

@@ -65,7 +65,7 @@ def _iterative_unlearn_impl(unlearn_iter_func):
         milestones = [int(x) for x in str(args.decreasing_lr).split(",")]
         arena = arena_of(model)
         optimizer = FusedMaskedSGD(arena, args.unlearn_lr, momentum=args.momentum, weight_decay=args.weight_decay)
-        if mask:
+        if mask and not getattr(unlearn_iter_func, "_ignores_mask", False):
             optimizer.set_mask(arena.pack_mask(mask))
         scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=milestones, gamma=0.1)
         for epoch in range(0, args.unlearn_epochs):

@@ -237,6 +237,69 @@ class Diffusion(object):
                 torch.save(states, os.path.join(config.ckpt_dir, "ckpt.pth"))
         return model
 
+    # ---------------------------------------------- EWC / Selective Amnesia
+    def forget_step(self, model, optimizer, remember_batch, fisher_flat, params_mle_flat):
+        """One iteration of the reference's `train_forget` body (runners/diffusion.py:313-365):
+        eps-MSE on uniform-noise images labelled with the class to forget + gamma * eps-MSE on the remember batch
+        (both without label dropout, one shared antithetic t), plus  lmbda * sum F (theta - theta*)^2.
+        The EWC term is not built in autograd: after the U-Net backward, `salun_ewc_penalty_grad` adds its gradient
+        into the flat gradient (one launch instead of 334 x 4 tensor ops) — before the clip, as in the reference,
+        where the clip sees the sum of both gradients.  Returns (loss, forgetting_loss, ewc_loss) tensors."""
+        args, config = self.args, self.config
+        b = self.betas
+        x_remember, c_remember = remember_batch
+        x_remember, c_remember = x_remember.to(self.device), c_remember.to(self.device)
+        x_remember = data_transform(config, x_remember)
+        n = x_remember.size(0)
+        c_forget = (torch.ones(n, dtype=int) * args.label_to_forget).to(self.device)
+        x_forget = (torch.rand((n, config.data.channels, config.data.image_size, config.data.image_size),
+                               device=self.device) - 0.5) * 2.0
+        e_remember = torch.randn_like(x_remember)
+        e_forget = torch.randn_like(x_forget)
+        t = antithetic_timesteps(n, self.num_timesteps, self.device)
+        loss_fn = loss_registry_conditional[config.model.type]
+        forgetting = loss_fn(model, x_forget, t, c_forget, e_forget, b, cond_drop_prob=0.0) + \
+            config.training.gamma * loss_fn(model, x_remember, t, c_remember, e_remember, b, cond_drop_prob=0.0)
+        optimizer.zero_grad()
+        forgetting.backward()
+        arena = optimizer.arena
+        ewc = ops.ewc_penalty_grad(arena.params, params_mle_flat, fisher_flat, arena.grads, config.training.lmbda)
+        optimizer.clip_grad_norm_(config.optim.grad_clip)
+        optimizer.step()
+        return forgetting.detach() + ewc[0], forgetting.detach(), ewc[0]
+
+    def train_forget(self, remember_loader=None, fisher_dict=None):
+        """`--mode forget`: contrastive forgetting with the EWC anchor (reference :273-396).  `fisher_dict` defaults
+        to {ckpt_folder}/fisher_dict.pkl (written by save_fim); `remember_loader` defaults to the all-but-one-class
+        sample folder (synthetic remain set with --synthetic)."""
+        args, config = self.args, self.config
+        logging.info(f"Training diffusion forget with contrastive and EWC. Gamma: {config.training.gamma}, "
+                     f"lambda: {config.training.lmbda}")
+        if remember_loader is None:
+            remember_loader, _ = self._loaders()
+        remember_iter = cycle(remember_loader)
+        model = self._load_model()
+        arena = arena_of(model)
+        optimizer = get_optimizer(config, arena=arena)
+        if config.model.ema:
+            raise NotImplementedError("EMA is off in the shipped configs (out of scope, SURVEY.md §2 D6)")
+        if fisher_dict is None:
+            with open(os.path.join(args.ckpt_folder, "fisher_dict.pkl"), "rb") as f:
+                fisher_dict = pickle.load(f)
+        fisher_flat = arena.pack(strip_prefix(fisher_dict))
+        params_mle_flat = arena.params.clone()
+        for step in range(0, config.training.n_iters):
+            model.train()
+            loss, forgetting_loss, ewc_loss = self.forget_step(model, optimizer, next(remember_iter), fisher_flat,
+                                                               params_mle_flat)
+            if (step + 1) % config.training.log_freq == 0:
+                logging.info(f"step: {step}, loss: {loss.item()}, forgetting loss: {forgetting_loss.item()}, "
+                             f"ewc loss: {ewc_loss.item()}")
+            if (step + 1) % config.training.snapshot_freq == 0 and sdist.rank() == 0:
+                states = [add_prefix(model.state_dict()), optimizer.state_dict(), step]
+                torch.save(states, os.path.join(config.ckpt_dir, "ckpt.pth"))
+        return model
+
     # ------------------------------------------------------------------ Fisher
     def save_fim(self, samples=None):
         """F = (1/N) Σ_samples (Σ_t ∇ℓ_t(x, c))²  (reference :101-191): per sample, the ε-MSE gradient is summed

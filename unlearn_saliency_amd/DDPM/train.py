@@ -90,9 +90,11 @@ def main(argv=None):
             runner.saliency_unlearn()
         elif args.mode == "generate_mask":
             runner.generate_mask()
+        elif args.mode == "forget":  # EWC / Selective Amnesia on the fused penalty kernel
+            runner.train_forget()
         else:
-            raise NotImplementedError(f"--mode {args.mode}: pre-training / EWC / retrain are outside the SalUn hot "
-                                      "path of this build (SURVEY.md §2 D1, §8 F3)")
+            raise NotImplementedError(f"--mode {args.mode}: pre-training / retrain are outside the SalUn hot "
+                                      "path of this build (SURVEY.md §2 D1)")
     except Exception:
         logging.error(traceback.format_exc())
         return 1

@@ -60,6 +60,10 @@ SIGNATURES = {
     "salun_bn_forward": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_double, c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_bn_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_backward_data_add": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "salun_param_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "salun_soft_threshold_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "salun_ewc_workspace_bytes": (c_size_t, [c_int64]),
+    "salun_ewc_penalty_grad": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "salun_image_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                   c_int, c_void_p]),
     "salun_fill_uniform": (c_int, [c_void_p, c_int64, c_uint64, c_double, c_double, c_void_p]),

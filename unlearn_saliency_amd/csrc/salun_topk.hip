@@ -183,7 +183,7 @@ __global__ __launch_bounds__(1024) void k_select(TopkState *st, int64_t n, KList
     if ((int)threadIdx.x < nk) {
       k = kl.k[threadIdx.x];
       if (k <= 0) { k = 0; mode = MODE_NONE; }
-      else if (k >= n) { k = n; mode = MODE_ALL; }
+      else if (k > n) { k = n; mode = MODE_ALL; }  // k == n runs the select: its threshold (the minimum) is real
       else mode = MODE_GE;  // provisional: refined after the last level
     }
     st->k[threadIdx.x] = k;

@@ -76,6 +76,17 @@ class FlatArena:
         return OrderedDict((prefix + n, flat[o:o + k].view(shp))
                            for n, o, k, shp in zip(self.names, self.offsets, self.numels, self.shapes))
 
+    def pack(self, tensors: Dict[str, torch.Tensor], prefix: str = "") -> torch.Tensor:
+        """name -> fp32 tensor dict (e.g. the Fisher dictionary of DDPM/runners/diffusion.py:177-191) -> one flat
+        device vector in arena order.  Every parameter must be present with its shape."""
+        out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        for n, o, k, shp in zip(self.names, self.offsets, self.numels, self.shapes):
+            t = tensors[prefix + n]
+            if tuple(t.shape) != tuple(shp):
+                raise ValueError(f"{prefix + n}: shape {tuple(t.shape)} != parameter shape {tuple(shp)}")
+            out[o:o + k] = t.reshape(-1).to(device=self.device, dtype=torch.float32)
+        return out
+
     def new_like(self, dtype=torch.float32, zero: bool = True) -> torch.Tensor:
         f = torch.zeros if zero else torch.empty
         return f(self.n, dtype=dtype, device=self.device)

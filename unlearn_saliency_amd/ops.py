@@ -308,6 +308,42 @@ def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, want_dres, gamma_
     return dx, dres, dgamma, dbeta
 
 
+# ------------------------------------------------------------------------ K9 / K10
+def proximal_step(p: torch.Tensor, p0: torch.Tensor, ratio: int, scratch: Optional[torch.Tensor] = None,
+                  scratch_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """In place soft-threshold of `p` towards `p0` with threshold = the ratio-th smallest |p - p0|
+    (RL_pro.py:52-60).  Returns the threshold as a 1-element device tensor (no host sync)."""
+    n = p.numel()
+    if ratio < 1:
+        raise IndexError("index -1 is out of bounds for dimension 0 with size 0")  # reference: topk(.., 0)[0][-1]
+    if ratio > n:
+        raise RuntimeError("selected index k out of range")  # reference: torch.topk with k > n
+    L = _lib.lib()
+    d = scratch if scratch is not None else torch.empty(n, dtype=torch.float32, device=p.device)
+    check(L.salun_param_diff(_dev(p, torch.float32, "p"), _dev(p0, torch.float32, "p0"), _dev(d, torch.float32, "d"),
+                             c_int64(n), _stream()), "salun_param_diff")
+    m = scratch_mask if scratch_mask is not None else torch.empty(n, dtype=torch.uint8, device=p.device)
+    mask_topk(d, [n - ratio + 1], out=[m])  # k-th largest |d| with k = n - ratio + 1 == ratio-th smallest
+    tau = mask_topk_thresholds(p.device, 1)
+    check(L.salun_soft_threshold_step(_dev(p, torch.float32, "p"), _dev(p0, torch.float32, "p0"),
+                                      c_void_p(tau.data_ptr()), c_int64(n), _stream()), "salun_soft_threshold_step")
+    return tau
+
+
+def ewc_penalty_grad(p: torch.Tensor, p_star: torch.Tensor, F: torch.Tensor, g: torch.Tensor, lam: float
+                     ) -> torch.Tensor:
+    """g += grad of lam * sum F (p - p*)^2; returns device tensor [lam * S, S]."""
+    n = p.numel()
+    L = _lib.lib()
+    out = torch.empty(2, dtype=torch.float32, device=p.device)
+    ws = workspace(L.salun_ewc_workspace_bytes(c_int64(n)), p.device)
+    check(L.salun_ewc_penalty_grad(_dev(p, torch.float32, "p"), _dev(p_star, torch.float32, "p_star"),
+                                   _dev(F, torch.float32, "F"), _dev(g, torch.float32, "g"), c_double(lam),
+                                   c_void_p(out.data_ptr()), c_int64(n), c_void_p(ws.data_ptr()),
+                                   c_size_t(ws.numel()), _stream()), "salun_ewc_penalty_grad")
+    return out
+
+
 # ----------------------------------------------------------------------------- K0
 def image_batch(data: torch.Tensor, idx: torch.Tensor, crop: Optional[torch.Tensor] = None,
                 flip: Optional[torch.Tensor] = None, pad: int = 4, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -43,7 +43,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SALUN_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices): used by the
+            # single-GPU smoke test of the data-parallel path, never for performance
+            backend = os.environ.get("SALUN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())

@@ -26,6 +26,9 @@ SHAPES = [
     (4, 384, 16, 256, 3, 1, 1),   # DDPM up-block with concatenated skip
     (4, 128, 32, 3, 3, 1, 1),     # DDPM conv_out (K = 3: masked channel tile)
     (2, 40, 16, 72, 3, 1, 1),     # channel counts that are not multiples of 32
+    (8, 3, 32, 64, 3, 2, 1),      # small-C backward-weight kernel, stride 2
+    (5, 1, 16, 40, 3, 1, 1),      # single input channel, ragged N and K
+    (6, 4, 64, 320, 3, 1, 1),     # SD conv_in (C = 4 latents)
 ]
 
 

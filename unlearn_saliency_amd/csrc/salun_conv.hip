@@ -701,6 +701,117 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
   }
 }
 
+// backward-weight for tiny input-channel counts (the RGB stem: C*R*R <= 32).  The general kernel would spend a
+// 64-channel tile and R*R accumulators on 3 real channels; here the 32 MFMA columns are the (c, r, s) combinations
+// themselves (27 for RGB 3x3), one accumulator per wave, and the kernel is bound by reading dY once.
+// Workgroup: 4 waves = 2 k-tiles x 2 halves of the chunk's pixel pairs; partial slot = split*2 + half.
+template <int R, int STRIDE>
+__global__ __launch_bounds__(256) void conv_wgrad_smallc(const float *__restrict__ x, const float *__restrict__ dy,
+                                                         float *__restrict__ part, int N, int C, int H, int W, int K,
+                                                         int P, int Q, int pad, int NI, int TP, int IH_t, int IW_t,
+                                                         int logQ, int nchunks) {
+  constexpr int RS = R * R;
+  constexpr int PIXC = (STRIDE == 1) ? 64 : 32;
+  constexpr int DROW = PIXC + 1;
+  constexpr int NSTEP = PIXC / 2;
+  constexpr int DN4 = 64 * PIXC / 4 / 256;
+  constexpr int LOGPIX4 = (PIXC == 64) ? 4 : 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int PSZ = NI * IH_t * IW_t;
+  const int ch_stride = PSZ | 1;
+  float *xp = lds;                  // [C][ch_stride]
+  float *dl = lds + C * ch_stride;  // [64 k][DROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int kt = wave & 1, half = wave >> 1;
+  const int k0 = blockIdx.x * 64;
+  const int split = blockIdx.z, nsplit = gridDim.z;
+  const int tiles_per_img = (NI > 1) ? 1 : P / TP;
+  const int planeHW = H * W, PQ = P * Q;
+  const int logTP = __builtin_ctz(TP);
+  const int ncol = C * RS;  // real MFMA columns (<= 32)
+
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+
+  // this lane's column: (c, r, s) and its offset inside the staged patch
+  const int col_c = lo / RS, col_rs = lo - col_c * RS;
+  const int col_r = col_rs / R, col_s = col_rs - col_r * R;
+  const bool col_ok = lo < ncol;
+  const int lane_off = col_ok ? (col_c * ch_stride + col_r * IW_t + col_s + hi * STRIDE) : 0;
+  const unsigned bmask = col_ok ? 0xffffffffu : 0u;
+  // patch position staged by this thread
+  const int e_ni = tid / (IH_t * IW_t);
+  const int e_rem = tid - e_ni * (IH_t * IW_t);
+  const int e_ih = e_rem / IW_t, e_iw = e_rem - e_ih * IW_t;
+  const int ww = -pad + e_iw;
+
+  for (int chunk = split; chunk < nchunks; chunk += nsplit) {
+    int n0, p0;
+    if (NI > 1) { n0 = chunk * NI; p0 = 0; }
+    else { n0 = chunk / tiles_per_img; p0 = (chunk - n0 * tiles_per_img) * TP; }
+    // ---- global -> registers
+    float xr[4];
+    {
+      const int n = n0 + e_ni;
+      const int h = p0 * STRIDE - pad + e_ih;
+      const bool ok = tid < PSZ && n < N && h >= 0 && h < H && ww >= 0 && ww < W;
+      const float *src = x + (ok ? ((size_t)n * C * planeHW + (size_t)h * W + ww) : 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xr[c] = (ok && c < C) ? src[(size_t)c * planeHW] : 0.f;
+    }
+    float4 dr[DN4];
+#pragma unroll
+    for (int i = 0; i < DN4; ++i) {
+      const int e4 = tid + i * 256;
+      const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4;
+      const int q = m & (Q - 1), pr = m >> logQ;
+      const int ni = pr >> logTP, pl = pr & (TP - 1);
+      const int n = n0 + ni;
+      const bool okd = n < N && (k0 + kk) < K;
+      dr[i] = okd ? *reinterpret_cast<const float4 *>(dy + ((size_t)n * K + (k0 + kk)) * PQ + (size_t)(p0 + pl) * Q + q)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();  // previous chunk fully consumed
+    if (tid < PSZ) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) xp[c * ch_stride + tid] = xr[c];
+    }
+#pragma unroll
+    for (int i = 0; i < DN4; ++i) {
+      const int e4 = tid + i * 256;
+      const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4;
+      float *d = dl + kk * DROW + m;
+      d[0] = dr[i].x; d[1] = dr[i].y; d[2] = dr[i].z; d[3] = dr[i].w;
+    }
+    __syncthreads();
+    const float *arow = dl + (kt * 32 + lo) * DROW + hi;
+    const float *brow = xp + lane_off;
+#pragma unroll
+    for (int st = 0; st < NSTEP / 2; ++st) {
+      const int j = 2 * (half * (NSTEP / 2) + st);
+      const int q0 = j & (Q - 1), pr = j >> logQ;
+      const int ni = pr >> logTP, pl = pr & (TP - 1);
+      const int off = (ni * IH_t + pl * STRIDE) * IW_t + q0 * STRIDE;
+      const float a = arow[j];
+      const float b = __uint_as_float(__float_as_uint(brow[off]) & bmask);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  // partial[split*2 + half][rs][k][c]
+  float *out = part + (size_t)(split * 2 + half) * K * C * RS;
+  if (col_ok) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int k = k0 + kt * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+      if (k < K) out[((size_t)col_rs * K + k) * C + col_c] = acc[v];
+    }
+  }
+}
+
 // dw (+)= sum_s part[s] in a fixed order: 8 strided sub-sums per output (thread g sums s = g, g+8, ...), folded
 // g = 0..7 through LDS.  32 outputs x 8 groups per workgroup keeps thousands of waves with loads in flight instead
 // of one long serial chain per output.  Partials are [rs][k][c]; the result is written in OIHW.
@@ -977,7 +1088,14 @@ SALUN_EXPORT size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int 
   TileGeom g = make_geom(N, P, Q, 32, 1, R);
   if (!g.ok) g = make_geom(N, P, Q, 64, 1, R);
   if (!g.ok) return 0;
-  const int ns = wgrad_nsplit(K, C, g.ntiles);
+  int ns = wgrad_nsplit(K, C, g.ntiles);
+  if (C * R * R <= 32 && C <= 4) {  // small-C kernel: up to 1024 workgroups x 2 pixel halves
+    int nss = 1024 / ((K + 63) / 64);
+    TileGeom g64 = make_geom(N, P, Q, 64, 1, R);
+    const int nt = g64.ok && g64.ntiles > g.ntiles ? g64.ntiles : g.ntiles;
+    if (nss > nt) nss = nt;
+    if (nss * 2 > ns) ns = nss * 2;
+  }
   return sizeof(float) * (size_t)ns * K * C * R * R;
 }
 
@@ -990,10 +1108,35 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
   const int pixc = (stride == 1) ? 64 : 32;
   TileGeom g = make_geom(N, P, Q, pixc, stride, R);
   if (!g.ok || g.NI * g.IH_t * g.IW_t > 256) return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  if (C * R * R <= 32 && C <= 4 && Q >= 4 && (g.TP & (g.TP - 1)) == 0) {  // RGB stem: columns = (c, r, s)
+    int ns = 1024 / ((K + 63) / 64);
+    if (ns > g.ntiles) ns = g.ntiles;
+    if (ns < 1) ns = 1;
+    const size_t need_s = sizeof(float) * (size_t)ns * 2 * K * C * R * R;
+    if (ws_bytes < need_s) return SALUN_ENOSPC;
+    const int PSZs = g.NI * g.IH_t * g.IW_t;
+    const size_t ldss = sizeof(float) * ((size_t)C * (PSZs | 1) + (size_t)64 * (pixc + 1));
+    dim3 grid_s((K + 63) / 64, 1, ns);
+    float *part_s = static_cast<float *>(ws);
+#define SALUN_WGRAD_S(R_, S_)                                                                                  \
+  hipLaunchKernelGGL((conv_wgrad_smallc<R_, S_>), grid_s, dim3(256), ldss, st, x, dy, part_s, N, C, H, W, K, P, \
+                     Q, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles)
+    if (R == 3 && stride == 1) SALUN_WGRAD_S(3, 1);
+    else if (R == 3 && stride == 2) SALUN_WGRAD_S(3, 2);
+    else if (R == 1 && stride == 1) SALUN_WGRAD_S(1, 1);
+    else SALUN_WGRAD_S(1, 2);
+#undef SALUN_WGRAD_S
+    SALUN_LAUNCH_CHECK();
+    const int64_t nn = (int64_t)K * C * R * R;
+    hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((nn + 31) / 32)), dim3(256), 0, st, part_s, dw, nn, ns * 2,
+                       accumulate, K * C, R * R);
+    SALUN_LAUNCH_CHECK();
+    return SALUN_OK;
+  }
   const int ns = wgrad_nsplit(K, C, g.ntiles);
   const size_t need = sizeof(float) * (size_t)ns * K * C * R * R;
   if (ws_bytes < need) return SALUN_ENOSPC;
-  hipStream_t st = salun_hip_stream(stream);
   const int PSZ = g.NI * g.IH_t * g.IW_t;
   if (Q < 4 || (g.TP & (g.TP - 1)) != 0) return SALUN_EINVAL;  // float4 dy staging; shift-only pixel decoding
   const size_t ldsb = sizeof(float) * 2 * ((size_t)64 * (PSZ | 1) + (size_t)64 * (pixc + 1) + 256);  // double buffered

@@ -43,59 +43,83 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float *__restric
   }
 }
 
-__global__ void k_bn_stats_final(const double *__restrict__ partial, int C, int nsplit, double M, float eps,
-                                 float momentum, float *__restrict__ mean, float *__restrict__ invstd,
-                                 float *__restrict__ running_mean, float *__restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
-    s1 += partial[((size_t)c * nsplit + s) * 2 + 0];
-    s2 += partial[((size_t)c * nsplit + s) * 2 + 1];
+// Per-channel statistics from the fp64 partials, computed redundantly by every workgroup of the channel (nsplit <= 64
+// values: one wave, fixed order) — no separate finalise launch.  Slice 0 publishes them and updates the running stats.
+__device__ __forceinline__ void bn_channel_stats(const double *__restrict__ partial, int c, int nsplit, double M,
+                                                 float eps, float *s_out /*LDS: mean, invstd*/, bool publish,
+                                                 float momentum, float *__restrict__ mean, float *__restrict__ invstd,
+                                                 float *__restrict__ running_mean, float *__restrict__ running_var) {
+  if (threadIdx.x < 64) {
+    double s1 = 0.0, s2 = 0.0;
+    if ((int)threadIdx.x < nsplit) {
+      s1 = partial[((size_t)c * nsplit + threadIdx.x) * 2 + 0];
+      s2 = partial[((size_t)c * nsplit + threadIdx.x) * 2 + 1];
+    }
+    s1 = salun_wave_sum(s1);
+    s2 = salun_wave_sum(s2);
+    if (threadIdx.x == 0) {
+      const double mu = s1 / M;
+      double var = s2 / M - mu * mu;
+      if (var < 0.0) var = 0.0;
+      const float is = (float)(1.0 / sqrt(var + (double)eps));
+      s_out[0] = (float)mu;
+      s_out[1] = is;
+      if (publish) {
+        mean[c] = (float)mu;
+        invstd[c] = is;
+        if (running_mean) {
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+          const double unbiased = (M > 1.0) ? var * M / (M - 1.0) : var;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+      }
+    }
   }
-  const double mu = s1 / M;
-  double var = s2 / M - mu * mu;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)mu;
-  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-    const double unbiased = (M > 1.0) ? var * M / (M - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
+  __syncthreads();
 }
 
-// eval mode: mean / invstd from the running statistics
-__global__ void k_bn_eval_params(const float *__restrict__ running_mean, const float *__restrict__ running_var, int C,
-                                 float eps, float *__restrict__ mean, float *__restrict__ invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  mean[c] = running_mean[c];
-  invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
-}
-
-template <bool RELU, bool RES>
+// y = [relu](gamma*(x-mean)*invstd + beta [+ res]) for channel blockIdx.x, batch slice blockIdx.y.
+// TRAIN: mean/invstd come from the partial sums (see above); else from the running statistics.
+template <bool RELU, bool RES, bool TRAIN>
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, const float *__restrict__ res,
-                                                  float *__restrict__ y, const float *__restrict__ mean,
-                                                  const float *__restrict__ invstd, const float *__restrict__ gamma,
-                                                  const float *__restrict__ beta, int C, int HW, int64_t total4) {
+                                                  float *__restrict__ y, const double *__restrict__ partial,
+                                                  float *__restrict__ mean, float *__restrict__ invstd,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                  int N, int C, int HW, int nsplit, float eps, float momentum) {
+  __shared__ float st[2];
+  const int c = blockIdx.x, s = blockIdx.y;
+  if (TRAIN) {
+    bn_channel_stats(partial, c, nsplit, (double)N * HW, eps, st, s == 0, momentum, mean, invstd, running_mean,
+                     running_var);
+  } else {
+    if (threadIdx.x == 0) {
+      st[0] = running_mean[c];
+      st[1] = 1.0f / sqrtf(running_var[c] + eps);
+      if (s == 0) { mean[c] = st[0]; invstd[c] = st[1]; }
+    }
+    __syncthreads();
+  }
+  const float a = st[1] * gamma[c];
+  const float b = beta[c] - st[0] * a;
+  const int n_lo = (int)((int64_t)N * s / nsplit), n_hi = (int)((int64_t)N * (s + 1) / nsplit);
   const int hw4 = HW >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)((i / hw4) % C);
-    const float a = invstd[c] * gamma[c];
-    const float b = beta[c] - mean[c] * a;
-    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+  const int work = (n_hi - n_lo) * hw4;
+  for (int e = threadIdx.x; e < work; e += 256) {
+    const int n = n_lo + e / hw4, i = e - (e / hw4) * hw4;
+    const size_t off = ((size_t)n * C + c) * HW;
+    const float4 v = reinterpret_cast<const float4 *>(x + off)[i];
     float4 o;
     o.x = v.x * a + b; o.y = v.y * a + b; o.z = v.z * a + b; o.w = v.w * a + b;
     if (RES) {
-      const float4 r = reinterpret_cast<const float4 *>(res)[i];
+      const float4 r = reinterpret_cast<const float4 *>(res + off)[i];
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     if (RELU) {
       o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
       o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
     }
-    reinterpret_cast<float4 *>(y)[i] = o;
+    reinterpret_cast<float4 *>(y + off)[i] = o;
   }
 }
 
@@ -137,46 +161,59 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict_
   }
 }
 
-__global__ void k_bn_bwd_final(const double *__restrict__ partial, int C, int nsplit, float *__restrict__ dgamma,
-                               float *__restrict__ dbeta, float *__restrict__ gacc, float *__restrict__ bacc) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
-    s1 += partial[((size_t)c * nsplit + s) * 2 + 0];
-    s2 += partial[((size_t)c * nsplit + s) * 2 + 1];
-  }
-  dbeta[c] = (float)s1;
-  dgamma[c] = (float)s2;
-  if (gacc) gacc[c] += (float)s2;  // optional: accumulate straight into the parameters' .grad storage
-  if (bacc) bacc[c] += (float)s1;
-}
-
+// dx (and dres) for channel blockIdx.x, batch slice blockIdx.y; dbeta / dgamma are folded from the partials by every
+// workgroup of the channel (fixed order), slice 0 publishes them (and accumulates into the parameters' .grad).
 template <bool RELU, bool TRAIN, bool DRES>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
                                                       const float *__restrict__ x, const float *__restrict__ mean,
                                                       const float *__restrict__ invstd,
                                                       const float *__restrict__ gamma,
-                                                      const float *__restrict__ dgamma,
-                                                      const float *__restrict__ dbeta, float *__restrict__ dx,
-                                                      float *__restrict__ dres, int C, int HW, float inv_m,
-                                                      int64_t total4) {
+                                                      const double *__restrict__ partial, float *__restrict__ dgamma,
+                                                      float *__restrict__ dbeta, float *__restrict__ gacc,
+                                                      float *__restrict__ bacc, float *__restrict__ dx,
+                                                      float *__restrict__ dres, int N, int C, int HW, int nsplit,
+                                                      float inv_m) {
+  __shared__ float sg[2];
+  const int c = blockIdx.x, s = blockIdx.y;
+  if (threadIdx.x < 64) {
+    double s1 = 0.0, s2 = 0.0;
+    if ((int)threadIdx.x < nsplit) {
+      s1 = partial[((size_t)c * nsplit + threadIdx.x) * 2 + 0];
+      s2 = partial[((size_t)c * nsplit + threadIdx.x) * 2 + 1];
+    }
+    s1 = salun_wave_sum(s1);
+    s2 = salun_wave_sum(s2);
+    if (threadIdx.x == 0) {
+      sg[0] = (float)s1;  // dbeta
+      sg[1] = (float)s2;  // dgamma
+      if (s == 0) {
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        if (gacc) gacc[c] += (float)s2;  // optional: accumulate straight into the parameters' .grad storage
+        if (bacc) bacc[c] += (float)s1;
+      }
+    }
+  }
+  __syncthreads();
+  const float mu = mean[c], is = invstd[c];
+  const float gi = gamma[c] * is;
+  const float kb = sg[0] * inv_m, kg = sg[1] * inv_m;
+  const int n_lo = (int)((int64_t)N * s / nsplit), n_hi = (int)((int64_t)N * (s + 1) / nsplit);
   const int hw4 = HW >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)((i / hw4) % C);
-    const float mu = mean[c], is = invstd[c];
-    const float gi = gamma[c] * is;
-    float4 g = reinterpret_cast<const float4 *>(dy)[i];
+  const int work = (n_hi - n_lo) * hw4;
+  for (int e = threadIdx.x; e < work; e += 256) {
+    const int n = n_lo + e / hw4, i = e - (e / hw4) * hw4;
+    const size_t off = ((size_t)n * C + c) * HW;
+    float4 g = reinterpret_cast<const float4 *>(dy + off)[i];
     if (RELU) {
-      const float4 yv = reinterpret_cast<const float4 *>(y)[i];
+      const float4 yv = reinterpret_cast<const float4 *>(y + off)[i];
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
       g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     }
-    if (DRES) reinterpret_cast<float4 *>(dres)[i] = g;
+    if (DRES) reinterpret_cast<float4 *>(dres + off)[i] = g;
     float4 o;
     if (TRAIN) {
-      const float4 xv = reinterpret_cast<const float4 *>(x)[i];
-      const float kb = dbeta[c] * inv_m, kg = dgamma[c] * inv_m;
+      const float4 xv = reinterpret_cast<const float4 *>(x + off)[i];
       o.x = gi * (g.x - (kb + ((xv.x - mu) * is) * kg));
       o.y = gi * (g.y - (kb + ((xv.y - mu) * is) * kg));
       o.z = gi * (g.z - (kb + ((xv.z - mu) * is) * kg));
@@ -184,7 +221,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
     } else {
       o.x = gi * g.x; o.y = gi * g.y; o.z = gi * g.z; o.w = gi * g.w;
     }
-    reinterpret_cast<float4 *>(dx)[i] = o;
+    reinterpret_cast<float4 *>(dx + off)[i] = o;
   }
 }
 
@@ -214,28 +251,26 @@ SALUN_EXPORT int salun_bn_forward(const float *x, const float *res, float *y, co
   if (!training && (!running_mean || !running_var)) return SALUN_EINVAL;
   if (!salun_aligned16(x) || !salun_aligned16(y) || (res && !salun_aligned16(res))) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
+  const int ns = bn_nsplit(N, C);
+  double *partial = static_cast<double *>(ws);
   if (training) {
     if (!ws || ws_bytes < salun_bn_workspace_bytes(C)) return SALUN_ENOSPC;
-    const int ns = bn_nsplit(N, C);
-    double *partial = static_cast<double *>(ws);
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(C, ns), dim3(256), 0, st, x, N, C, HW, ns, partial);
     SALUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, st, partial, C, ns, (double)N * HW,
-                       (float)eps, (float)momentum, save_mean, save_invstd, running_mean, running_var);
-    SALUN_LAUNCH_CHECK();
-  } else {
-    hipLaunchKernelGGL(k_bn_eval_params, dim3((C + 255) / 256), dim3(256), 0, st, running_mean, running_var, C,
-                       (float)eps, save_mean, save_invstd);
-    SALUN_LAUNCH_CHECK();
   }
-  const int64_t total4 = (int64_t)N * C * HW / 4;
-  const int grid = salun_grid_for(total4, 256 * 4);
-#define SALUN_BN_APPLY(RELU_, RES_) \
-  hipLaunchKernelGGL((k_bn_apply<RELU_, RES_>), dim3(grid), dim3(256), 0, st, x, res, y, save_mean, save_invstd, gamma, beta, C, HW, total4)
-  if (relu && res) SALUN_BN_APPLY(true, true);
-  else if (relu) SALUN_BN_APPLY(true, false);
-  else if (res) SALUN_BN_APPLY(false, true);
-  else SALUN_BN_APPLY(false, false);
+#define SALUN_BN_APPLY(RELU_, RES_, TRAIN_)                                                                       \
+  hipLaunchKernelGGL((k_bn_apply<RELU_, RES_, TRAIN_>), dim3(C, ns), dim3(256), 0, st, x, res, y, partial,         \
+                     save_mean, save_invstd, gamma, beta, running_mean, running_var, N, C, HW, ns, (float)eps,    \
+                     (float)momentum)
+  const bool r = relu != 0, a = res != nullptr, t = training != 0;
+  if (r && a && t) SALUN_BN_APPLY(true, true, true);
+  else if (r && a) SALUN_BN_APPLY(true, true, false);
+  else if (r && t) SALUN_BN_APPLY(true, false, true);
+  else if (r) SALUN_BN_APPLY(true, false, false);
+  else if (a && t) SALUN_BN_APPLY(false, true, true);
+  else if (a) SALUN_BN_APPLY(false, true, false);
+  else if (t) SALUN_BN_APPLY(false, false, true);
+  else SALUN_BN_APPLY(false, false, false);
 #undef SALUN_BN_APPLY
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
@@ -260,14 +295,11 @@ SALUN_EXPORT int salun_bn_backward(const float *dy, const float *y, const float 
   if (relu) hipLaunchKernelGGL(k_bn_bwd_partial<true>, dim3(C, ns), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, N, C, HW, ns, partial);
   else hipLaunchKernelGGL(k_bn_bwd_partial<false>, dim3(C, ns), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, N, C, HW, ns, partial);
   SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, partial, C, ns, dgamma, dbeta,
-                     grad_gamma_acc, grad_beta_acc);
-  SALUN_LAUNCH_CHECK();
-  const int64_t total4 = (int64_t)N * C * HW / 4;
-  const int grid = salun_grid_for(total4, 256 * 4);
   const float inv_m = (float)(1.0 / ((double)N * HW));
-#define SALUN_BN_BWD(RELU_, TRAIN_, DRES_) \
-  hipLaunchKernelGGL((k_bn_bwd_apply<RELU_, TRAIN_, DRES_>), dim3(grid), dim3(256), 0, st, dy, y, x, save_mean, save_invstd, gamma, dgamma, dbeta, dx, dres, C, HW, inv_m, total4)
+#define SALUN_BN_BWD(RELU_, TRAIN_, DRES_)                                                                          \
+  hipLaunchKernelGGL((k_bn_bwd_apply<RELU_, TRAIN_, DRES_>), dim3(C, ns), dim3(256), 0, st, dy, y, x, save_mean,   \
+                     save_invstd, gamma, partial, dgamma, dbeta, grad_gamma_acc, grad_beta_acc, dx, dres, N, C, HW, \
+                     ns, inv_m)
   const bool r = relu != 0, t = training != 0, d = dres != nullptr;
   if (r && t && d) SALUN_BN_BWD(true, true, true);
   else if (r && t) SALUN_BN_BWD(true, true, false);

@@ -42,6 +42,9 @@ struct ConvGeomUnused {
   int logQ, logTPQ;
 };
 
+// reduction channels per chunk of the rectangular-tap kernel (conv_igemm_tap): 32 / taps, at least 8
+constexpr int tap_chunk(int taps) { return taps == 1 ? 32 : taps == 2 ? 16 : 8; }
+
 // One staged patch position of a thread: where it comes from in a channel plane and where it goes in LDS.
 struct PatchPos {
   int goff;   // offset inside one (n, c) plane group: n*Cin*HW + ih*W + iw   (channel term added per chunk)
@@ -319,9 +322,11 @@ struct IgemmArgs {
   int rtop_h, rtop_w, ts;  // DGRAD tap mapping
 };
 
-template <int RH, int RW, int STRIDE, int KT, int WP, int WK, bool DGRAD>
+template <int RH, int RW, int STRIDE, int KT, int WP, int WK, bool DGRAD, int MAXPOS>
 __global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
   constexpr int RS = RH * RW;
+  constexpr int CC = tap_chunk(RS);    // reduction channels per chunk: 32 / 16 / 8 for 1 / 2 / 4 taps, so every chunk
+                                       // carries 16 k-steps between its barriers whatever the parity class
   constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
   constexpr int WROW = CC * RS + 1;    // LDS weight row (odd => conflict-free across 32 rows)
   constexpr int CONV_S = DGRAD ? 1 : STRIDE;
@@ -352,8 +357,7 @@ __global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
   const int ni_l = pr / TP, p_l = pr - ni_l * TP;
   const int pix_off = (ni_l * IH_t + p_l * CONV_S) * IW_t + q_l * CONV_S;  // tap (0,0) position in the patch
 
-  // ---- the (<= 3) patch positions this thread stages for every channel of a chunk
-  constexpr int MAXPOS = 3;
+  // ---- the (<= MAXPOS) patch positions this thread stages for every channel of a chunk
   PatchPos pos[MAXPOS];
   const int xC = g.xC, planeHW = g.xH * g.xW;
 #pragma unroll
@@ -449,22 +453,29 @@ __global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
     store_chunk();
     __syncthreads();
     if (c0 + CC < Cred) load_chunk(c0 + CC);  // in flight during the MFMA section below
-    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1)
+    // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1); the
+    // (1 + KT) LDS operands of k-step i+1 are read while the KT MFMAs of k-step i run (as in conv_igemm)
+    constexpr int NSTEP = (CC / 2) * RS;
+    const float *pb0 = patch + hi * ch_stride + pix_off;
+    const float *wb0 = wl + (wk * KT * 32 + lo) * WROW + hi * RS;
+    auto operands = [&](int step, float &bv, float (&av)[KT]) {
+      const int cc = 2 * (step / RS), rs = step % RS, r = rs / RW, s2 = rs % RW;  // compile-time after unrolling
+      bv = pb0[cc * ch_stride + r * IW_t + s2];
 #pragma unroll
-    for (int cc = 0; cc < CC; cc += 2) {
-      const float *pbase = patch + (cc + hi) * ch_stride + pix_off;
-      const float *wbase = wl + (wk * KT * 32 + lo) * WROW + (cc + hi) * RS;
+      for (int t = 0; t < KT; ++t) av[t] = wb0[t * 32 * WROW + cc * RS + rs];
+    };
+    float b_cur, a_cur[KT], b_nxt = 0.f, a_nxt[KT];
+    operands(0, b_cur, a_cur);
 #pragma unroll
-      for (int r = 0; r < RH; ++r)
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + 1 < NSTEP) operands(step + 1, b_nxt, a_nxt);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s2 = 0; s2 < RW; ++s2) {
-          const float b = pbase[r * IW_t + s2];
+      for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      b_cur = b_nxt;
 #pragma unroll
-          for (int t = 0; t < KT; ++t) {
-            const float a = wbase[t * 32 * WROW + r * RW + s2];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-          }
-        }
+      for (int t = 0; t < KT; ++t) a_cur[t] = a_nxt[t];
     }
   }
 
@@ -965,10 +976,16 @@ int launch_igemm_tap(IgemmArgs a, hipStream_t st) {
 #define SALUN_IGEMM(KT_, WP_, WK_)                                                                     \
   {                                                                                                    \
     constexpr int KB = WK_ * KT_ * 32;                                                                 \
-    const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));         \
+    constexpr int CCT = tap_chunk(RS);                                                                 \
+    const size_t ldsb = sizeof(float) * ((size_t)CCT * ch_stride + (size_t)KB * (CCT * RS + 1));       \
     dim3 grid(g.ntiles, (a.yC + KB - 1) / KB);                                                         \
-    allow_lds(conv_igemm_tap<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD>, ldsb);                                 \
-    hipLaunchKernelGGL((conv_igemm_tap<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD>), grid, dim3(256), ldsb, st, a); \
+    if (PSZ <= 256) {                                                                                  \
+      allow_lds(conv_igemm_tap<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD, 1>, ldsb);                        \
+      hipLaunchKernelGGL((conv_igemm_tap<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD, 1>), grid, dim3(256), ldsb, st, a); \
+    } else {                                                                                           \
+      allow_lds(conv_igemm_tap<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD, 3>, ldsb);                        \
+      hipLaunchKernelGGL((conv_igemm_tap<RH, RW, STRIDE, KT_, WP_, WK_, DGRAD, 3>), grid, dim3(256), ldsb, st, a); \
+    }                                                                                                  \
   }
   if (pixt == 128) {
     if (a.yC > 64) SALUN_IGEMM(4, 4, 1)

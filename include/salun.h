@@ -241,6 +241,26 @@ int salun_bn_backward(const float *dy /*dev*/, const float *y /*dev, needed if r
                       int N, int C, int HW, int training, int relu, void *ws /*dev*/, size_t ws_bytes,
                       salun_stream_t stream);
 
+/* Fused GroupNorm (+ SiLU), NCHW fp32, forward and backward — replaces the `nonlinearity(self.norm1(h))` chains of the
+ * diffusion U-Nets (DDPM/models/diffusion.py:36-41,118-128,340-352; SD ldm/modules/diffusionmodules/openaimodel.py
+ * ResBlock in_layers / out_layers) that run as ~6 library launches forward and ~9 backward per site.
+ *   forward : z = [silu]( gamma_c * (x - mean_{n,g}) * rstd_{n,g} + beta_c ),  rstd = 1/sqrt(var_biased + eps);
+ *             save_mean / save_rstd (N*G floats) are outputs
+ *   backward: dy = dz * silu'(y) with y recomputed from x;  dgamma_c = sum_{n,hw} dy*xhat,  dbeta_c = sum dy;
+ *             dx = rstd * (dy*gamma - mean_g(dy*gamma) - xhat * mean_g(dy*gamma*xhat))
+ * One workgroup per (image, group); HW must be a power of two >= 4, C % G == 0, pointers 16-B aligned.
+ * Reductions are in fixed order (deterministic).  Workspace (backward): salun_gn_workspace_bytes(N, C). */
+size_t salun_gn_workspace_bytes(int N, int C);
+int salun_gn_forward(const float *x /*dev*/, float *y /*dev*/, const float *gamma /*dev*/, const float *beta /*dev*/,
+                     float *save_mean /*dev*/, float *save_rstd /*dev*/, int N, int C, int HW, int G, double eps,
+                     int silu, salun_stream_t stream);
+int salun_gn_backward(const float *dz /*dev*/, const float *x /*dev*/, const float *gamma /*dev*/,
+                      const float *beta /*dev*/, const float *save_mean /*dev*/, const float *save_rstd /*dev*/,
+                      float *dx /*dev*/, float *dgamma /*dev*/, float *dbeta /*dev*/,
+                      float *grad_gamma_acc /*dev or NULL: += dgamma*/, float *grad_beta_acc /*dev or NULL*/,
+                      int N, int C, int HW, int G, int silu, void *ws /*dev*/, size_t ws_bytes,
+                      salun_stream_t stream);
+
 /* ------------------------------------------------------------------ K9 --
  * Proximal (soft-threshold) step of RL_proximal — Classification/unlearn/RL_pro.py:52-60:
  *     d = params - init_params ; threshold = -topk(-|d|, ratio)[0][-1] ;

@@ -135,3 +135,39 @@ def test_direct_grad_accumulation_equals_autograd_route():
         results.append(arena.grads.clone())
     a, b = results
     assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("shape,groups", [((8, 128, 32, 32), 32), ((4, 256, 16, 16), 32), ((4, 384, 16, 16), 32),
+                                          ((6, 512, 4, 4), 32), ((3, 64, 2, 2), 32), ((2, 320, 64, 64), 32),
+                                          ((2, 1920, 32, 32), 32), ((5, 96, 8, 8), 8)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_fused_group_norm_matches_torch(shape, groups, silu):
+    """GroupNorm(+SiLU) kernels vs torch's fp32 ops, forward and backward (cached and re-read modes, all segment
+    widths: H*W/4 from 1 to 1024 lanes per channel)."""
+    from unlearn_saliency_amd.norm import fused_gn_act
+    torch.manual_seed(0)
+    N, C, H, W = shape
+    x = (torch.randn(shape, device="cuda") * 1.5 + 0.3).requires_grad_(True)
+    gn = nn.GroupNorm(groups, C, eps=1e-6).cuda()
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5); gn.bias.normal_()
+    ref = nn.GroupNorm(groups, C, eps=1e-6).cuda()
+    ref.load_state_dict(gn.state_dict())
+    z = fused_gn_act(x, gn, silu=silu)
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = ref(x2)
+    z2 = y2 * torch.sigmoid(y2) if silu else y2
+    assert torch.allclose(z, z2, rtol=1e-4, atol=2e-5)
+    dz = torch.randn_like(z)
+    z.backward(dz); z2.backward(dz)
+    tol = lambda t: 2e-5 * float(t.abs().max()) + 1e-6
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=tol(x2.grad))
+    assert torch.allclose(gn.weight.grad, ref.weight.grad, rtol=1e-4, atol=tol(ref.weight.grad))
+    assert torch.allclose(gn.bias.grad, ref.bias.grad, rtol=1e-4, atol=tol(ref.bias.grad))
+    # second backward accumulates into .grad in the kernel (gradsink) — equals doubling
+    g1 = gn.weight.grad.clone()
+    fused_gn_act(x.detach().requires_grad_(True), gn, silu=silu).backward(dz)
+    assert torch.allclose(gn.weight.grad, 2 * g1, rtol=1e-5, atol=tol(g1))
+    # deterministic
+    a = fused_gn_act(x.detach(), gn, silu=silu)
+    assert torch.equal(a, fused_gn_act(x.detach(), gn, silu=silu))

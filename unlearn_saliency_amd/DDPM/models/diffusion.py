@@ -19,6 +19,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...norm import fused_gn_act
+
 
 def prob_mask_like(shape, prob, device):
     """Bernoulli(prob) boolean mask; exact all-True / all-False at prob 1 / 0 (no RNG consumed)."""
@@ -102,9 +104,9 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x, emb_act):
         """emb_act = swish([temb ‖ cemb]) — identical for every block, computed once per forward."""
-        h = self.conv1(swish(self.norm1(x)))
+        h = self.conv1(fused_gn_act(x, self.norm1, silu=True))  # swish(norm1(x)) as one kernel
         h = h + self.temb_cemb_proj(emb_act)[:, :, None, None]
-        h = self.conv2(self.dropout(swish(self.norm2(h))))
+        h = self.conv2(self.dropout(fused_gn_act(h, self.norm2, silu=True)))
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
         return x + h
@@ -124,7 +126,7 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         b, c, hh, ww = x.shape
-        h = self.norm(x)
+        h = fused_gn_act(x, self.norm, silu=False)
         tok = lambda t: t.reshape(b, 1, c, hh * ww).transpose(2, 3)  # (b, 1, hw, c)
         o = F.scaled_dot_product_attention(tok(self.q(h)), tok(self.k(h)), tok(self.v(h)), scale=float(c) ** -0.5)
         o = o.transpose(2, 3).reshape(b, c, hh, ww).contiguous()  # back to NCHW (the reshape alone is a channels-last view)
@@ -257,4 +259,4 @@ class Conditional_Model(nn.Module):
                     h = level.attn[i](h)
             if lvl != 0:
                 h = level.upsample(h)
-        return self.conv_out(swish(self.norm_out(h)))
+        return self.conv_out(fused_gn_act(h, self.norm_out, silu=True))

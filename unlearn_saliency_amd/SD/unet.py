@@ -21,6 +21,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint as _ckpt
 
+from ..norm import _GN_TYPES, fused_gn_act
+
 
 def timestep_embedding(timesteps, dim, max_period=10000):
     """[cos | sin] sinusoidal embedding (note: cosine first, unlike the DDPM model)."""
@@ -36,6 +38,9 @@ def timestep_embedding(timesteps, dim, max_period=10000):
 class GroupNorm32(nn.GroupNorm):
     def forward(self, x):
         return super().forward(x.float()).type(x.dtype)
+
+
+_GN_TYPES.add(GroupNorm32)  # fp32 evaluation is what the fused kernel does anyway
 
 
 def zero_module(m):
@@ -90,9 +95,12 @@ class ResBlock(nn.Module):
         self.skip_connection = nn.Identity() if out_channels == channels else nn.Conv2d(channels, out_channels, 1)
 
     def _forward(self, x, emb):
-        h = self.in_layers(x)
+        # GroupNorm32 -> SiLU as one kernel (norm.fused_gn_act; falls back to the library ops under autocast / for
+        # shapes outside the kernel's domain); the remaining layers of each Sequential run as they are
+        h = self.in_layers[2](fused_gn_act(x, self.in_layers[0], silu=True))
         h = h + self.emb_layers(emb).type(h.dtype)[..., None, None]
-        return self.skip_connection(x) + self.out_layers(h)
+        o = fused_gn_act(h, self.out_layers[0], silu=True)
+        return self.skip_connection(x) + self.out_layers[3](self.out_layers[2](o))
 
     def forward(self, x, emb):
         if self.use_checkpoint and torch.is_grad_enabled():
@@ -173,7 +181,7 @@ class SpatialTransformer(nn.Module):
 
     def forward(self, x, context=None):
         b, c, h, w = x.shape
-        t = self.proj_in(self.norm(x)).flatten(2).transpose(1, 2).contiguous()  # b (h w) c
+        t = self.proj_in(fused_gn_act(x, self.norm, silu=False)).flatten(2).transpose(1, 2).contiguous()  # b (h w) c
         for blk in self.transformer_blocks:
             t = blk(t, context)
         t = t.transpose(1, 2).reshape(b, -1, h, w).contiguous()
@@ -238,7 +246,7 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb, context)
         for module in self.output_blocks:
             h = module(torch.cat([h, hs.pop()], dim=1), emb, context)
-        return self.out(h.type(x.dtype))
+        return self.out[2](fused_gn_act(h.type(x.dtype), self.out[0], silu=True))
 
 
 V1_UNET_CONFIG = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1),

@@ -60,6 +60,9 @@ SIGNATURES = {
     "salun_bn_forward": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_double, c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_bn_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_backward_data_add": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "salun_gn_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "salun_gn_forward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_double, c_int, c_void_p]),
+    "salun_gn_backward": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "salun_param_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "salun_soft_threshold_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "salun_ewc_workspace_bytes": (c_size_t, [c_int64]),

@@ -313,3 +313,297 @@ SALUN_EXPORT int salun_bn_backward(const float *dy, const float *y, const float 
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }
+
+// ====================================================================================================
+// Fused GroupNorm (+ SiLU), NCHW fp32 — the `swish(norm(x))` prologue of every DDPM / SD ResNet block
+// (DDPM/models/diffusion.py:36-41,101-128; SD openaimodel.py ResBlock in_layers / out_layers).
+// One workgroup per (image, group): the group's (C/G)*HW values are contiguous.  Forward reads them once (kept in
+// registers when they fit: <= 64 values per lane), reduces sum / sum of squares, applies gamma/beta and SiLU, writes
+// once.  Backward recomputes y = gn(x) and sigma(y) instead of saving them, reduces the per-channel sums needed for
+// dgamma/dbeta (per-image partials, folded over the batch in a fixed order by a second small kernel) and the two
+// group sums of the input gradient, and writes dx — x and dz are read once.
+namespace {
+
+constexpr int GN_ITEMS = 16;            // float4 per lane held in registers (cached mode)
+constexpr int GN_MAX_SEG = 1024;        // LDS slots for segment sums
+
+__device__ __forceinline__ float gn_sigmoid(float y) { return 1.0f / (1.0f + expf(-y)); }
+
+// sum over aligned groups of `r` lanes (r a power of two <= 64); every lane of the group gets the total
+__device__ __forceinline__ float seg_sum(float v, int r) {
+  for (int off = 1; off < r; off <<= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <bool SILU, bool CACHED>
+__global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, float *__restrict__ y,
+                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                float *__restrict__ mean, float *__restrict__ rstd, int C, int HW,
+                                                int G, float eps) {
+  __shared__ double lds[4];
+  __shared__ float st[2];
+  const int ng = blockIdx.x, n = ng / G, g = ng - n * G;
+  const int cpg = C / G;
+  const int L = cpg * HW, nvec = L >> 2;
+  const size_t base = ((size_t)n * C + (size_t)g * cpg) * HW;
+  const float4 *xv = reinterpret_cast<const float4 *>(x + base);
+  float4 v[CACHED ? GN_ITEMS : 1];
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < GN_ITEMS; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < nvec) {
+        v[i] = xv[e];
+        s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+    }
+    d1 = s1; d2 = s2;
+  } else {
+    int it = 0;
+    for (int e = threadIdx.x; e < nvec; e += 256, ++it) {
+      const float4 t = xv[e];
+      s1 += (t.x + t.y) + (t.z + t.w);
+      s2 += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+      if ((it & 15) == 15) { d1 += s1; d2 += s2; s1 = 0.f; s2 = 0.f; }
+    }
+    d1 += s1; d2 += s2;
+  }
+  const double t1 = salun_block_sum(d1, lds);
+  const double t2 = salun_block_sum(d2, lds);
+  if (threadIdx.x == 0) {
+    const double mu = t1 / L;
+    double var = t2 / L - mu * mu;
+    if (var < 0.0) var = 0.0;
+    st[0] = (float)mu;
+    st[1] = (float)(1.0 / sqrt(var + (double)eps));
+    mean[ng] = st[0];
+    rstd[ng] = st[1];
+  }
+  __syncthreads();
+  const float mu = st[0], rs = st[1];
+  const int hw4 = HW >> 2;
+  float4 *yv = reinterpret_cast<float4 *>(y + base);
+  auto apply = [&](int e, float4 t) {
+    const int c = g * cpg + e / hw4;
+    const float a = rs * gamma[c];
+    const float b = beta[c] - mu * a;
+    float4 o;
+    o.x = t.x * a + b; o.y = t.y * a + b; o.z = t.z * a + b; o.w = t.w * a + b;
+    if (SILU) {
+      o.x = o.x * gn_sigmoid(o.x); o.y = o.y * gn_sigmoid(o.y);
+      o.z = o.z * gn_sigmoid(o.z); o.w = o.w * gn_sigmoid(o.w);
+    }
+    yv[e] = o;
+  };
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < GN_ITEMS; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < nvec) apply(e, v[i]);
+    }
+  } else {
+    for (int e = threadIdx.x; e < nvec; e += 256) apply(e, xv[e]);
+  }
+}
+
+// Backward.  seg: aligned run of r = min(HW/4, 64) lanes inside one channel; segment sums go to LDS, channel sums
+// are folded from them by one lane per channel, group sums from the channel sums — all in fixed order.
+template <bool SILU, bool CACHED>
+__global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, const float *__restrict__ x,
+                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                float *__restrict__ dx, float *__restrict__ part_dgamma,
+                                                float *__restrict__ part_dbeta, int C, int HW, int G) {
+  __shared__ float seg_g[GN_MAX_SEG], seg_b[GN_MAX_SEG];
+  __shared__ float grp[2];
+  const int ng = blockIdx.x, n = ng / G, g = ng - n * G;
+  const int cpg = C / G;
+  const int L = cpg * HW, nvec = L >> 2, hw4 = HW >> 2;
+  const size_t base = ((size_t)n * C + (size_t)g * cpg) * HW;
+  const float4 *xv = reinterpret_cast<const float4 *>(x + base);
+  const float4 *gv = reinterpret_cast<const float4 *>(dz + base);
+  const float mu = mean[ng], rs = rstd[ng];
+  const int r = hw4 < 64 ? hw4 : 64;          // lanes per segment (power of two)
+  const int segs_per_ch = hw4 / r;            // >= 1
+  float4 xc[CACHED ? GN_ITEMS : 1], dc[CACHED ? GN_ITEMS : 1];
+
+  // dy (gradient w.r.t. the normalised, affine output) of one float4, from x and dz
+  auto dy_of = [&](int e, float4 xt, float4 gt, float4 &xh) {
+    const int c = g * cpg + e / hw4;
+    const float ga = gamma[c], be = beta[c];
+    xh.x = (xt.x - mu) * rs; xh.y = (xt.y - mu) * rs; xh.z = (xt.z - mu) * rs; xh.w = (xt.w - mu) * rs;
+    if (SILU) {
+      const float y0 = xh.x * ga + be, y1 = xh.y * ga + be, y2 = xh.z * ga + be, y3 = xh.w * ga + be;
+      const float s0 = gn_sigmoid(y0), s1 = gn_sigmoid(y1), s2 = gn_sigmoid(y2), s3 = gn_sigmoid(y3);
+      gt.x = gt.x * (s0 * (1.0f + y0 * (1.0f - s0)));
+      gt.y = gt.y * (s1 * (1.0f + y1 * (1.0f - s1)));
+      gt.z = gt.z * (s2 * (1.0f + y2 * (1.0f - s2)));
+      gt.w = gt.w * (s3 * (1.0f + y3 * (1.0f - s3)));
+    }
+    return gt;
+  };
+  auto seg_accumulate = [&](int e, float4 dyv, float4 xh, bool valid) {
+    float sg = valid ? (dyv.x * xh.x + dyv.y * xh.y) + (dyv.z * xh.z + dyv.w * xh.w) : 0.f;
+    float sb = valid ? (dyv.x + dyv.y) + (dyv.z + dyv.w) : 0.f;
+    sg = seg_sum(sg, r);
+    sb = seg_sum(sb, r);
+    if (valid && (threadIdx.x & (r - 1)) == 0) {
+      seg_g[e / r] = sg;
+      seg_b[e / r] = sb;
+    }
+  };
+  const int nround = (nvec + 255) / 256;  // every lane walks the same number of rounds (shuffles need all lanes)
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < GN_ITEMS; ++i) {
+      if (i < nround) {
+        const int e = threadIdx.x + i * 256;
+        const bool valid = e < nvec;
+        float4 xh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+          xc[i] = xv[e];
+          dc[i] = dy_of(e, xc[i], gv[e], xh);
+        }
+        seg_accumulate(valid ? e : 0, valid ? dc[i] : xh, xh, valid);
+      }
+    }
+  } else {
+    for (int i = 0; i < nround; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const bool valid = e < nvec;
+      float4 xh = make_float4(0.f, 0.f, 0.f, 0.f), d = xh;
+      if (valid) d = dy_of(e, xv[e], gv[e], xh);
+      seg_accumulate(valid ? e : 0, d, xh, valid);
+    }
+  }
+  __syncthreads();
+  // channel sums (one lane per channel), published as per-image partials
+  float my_g = 0.f, my_b = 0.f;
+  if ((int)threadIdx.x < cpg) {
+    for (int s = 0; s < segs_per_ch; ++s) {
+      my_g += seg_g[threadIdx.x * segs_per_ch + s];
+      my_b += seg_b[threadIdx.x * segs_per_ch + s];
+    }
+    const int c = g * cpg + threadIdx.x;
+    part_dgamma[(size_t)n * C + c] = my_g;
+    part_dbeta[(size_t)n * C + c] = my_b;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < cpg) {  // reuse the segment arrays for the gamma-weighted channel sums
+    const float ga = gamma[g * cpg + threadIdx.x];
+    seg_g[threadIdx.x] = my_g * ga;
+    seg_b[threadIdx.x] = my_b * ga;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int c = 0; c < cpg; ++c) { b += seg_g[c]; a += seg_b[c]; }
+    grp[0] = a / (float)L;  // mean over the group of dy*gamma
+    grp[1] = b / (float)L;  // mean over the group of dy*gamma*xhat
+  }
+  __syncthreads();
+  const float ma = grp[0], mb = grp[1];
+  float4 *ov = reinterpret_cast<float4 *>(dx + base);
+  auto emit = [&](int e, float4 xt, float4 dyv) {
+    const float ga = gamma[g * cpg + e / hw4];
+    float4 o;
+    o.x = rs * (dyv.x * ga - ma - ((xt.x - mu) * rs) * mb);
+    o.y = rs * (dyv.y * ga - ma - ((xt.y - mu) * rs) * mb);
+    o.z = rs * (dyv.z * ga - ma - ((xt.z - mu) * rs) * mb);
+    o.w = rs * (dyv.w * ga - ma - ((xt.w - mu) * rs) * mb);
+    ov[e] = o;
+  };
+  if (CACHED) {
+#pragma unroll
+    for (int i = 0; i < GN_ITEMS; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < nvec) emit(e, xc[i], dc[i]);
+    }
+  } else {
+    for (int e = threadIdx.x; e < nvec; e += 256) {
+      float4 xh;
+      const float4 xt = xv[e];
+      emit(e, xt, dy_of(e, xt, gv[e], xh));
+    }
+  }
+}
+
+// dgamma[c] = sum_n part[n][c] (fixed order), optionally also accumulated into the parameter's .grad storage
+__global__ __launch_bounds__(256) void k_gn_bwd_final(const float *__restrict__ part_dgamma,
+                                                      const float *__restrict__ part_dbeta, int N, int C,
+                                                      float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                      float *__restrict__ gacc, float *__restrict__ bacc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sb = 0.0;
+  for (int n = 0; n < N; ++n) {
+    sg += (double)part_dgamma[(size_t)n * C + c];
+    sb += (double)part_dbeta[(size_t)n * C + c];
+  }
+  dgamma[c] = (float)sg;
+  dbeta[c] = (float)sb;
+  if (gacc) gacc[c] += (float)sg;
+  if (bacc) bacc[c] += (float)sb;
+}
+
+inline bool gn_shape_ok(int N, int C, int HW, int G) {
+  if (N < 1 || C < 1 || G < 1 || C % G != 0 || HW < 4 || (HW & (HW - 1)) != 0) return false;  // HW: power of two >= 4
+  const int cpg = C / G;
+  if (cpg > 256) return false;
+  const int hw4 = HW >> 2, r = hw4 < 64 ? hw4 : 64;
+  return (int64_t)cpg * hw4 / r <= GN_MAX_SEG && (int64_t)cpg * HW < (1 << 30);
+}
+
+}  // namespace
+
+SALUN_EXPORT size_t salun_gn_workspace_bytes(int N, int C) {
+  return sizeof(float) * 2 * (size_t)(N > 0 ? N : 0) * (size_t)(C > 0 ? C : 0);
+}
+
+// y = [silu](GroupNorm(x; G groups, gamma, beta, eps)); save_mean / save_rstd: N*G floats (outputs, for backward)
+SALUN_EXPORT int salun_gn_forward(const float *x, float *y, const float *gamma, const float *beta, float *save_mean,
+                                  float *save_rstd, int N, int C, int HW, int G, double eps, int silu,
+                                  salun_stream_t stream) {
+  if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !gn_shape_ok(N, C, HW, G)) return SALUN_EINVAL;
+  if (!salun_aligned16(x) || !salun_aligned16(y)) return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  const bool cached = (int64_t)(C / G) * HW / 4 <= (int64_t)GN_ITEMS * 256;
+#define SALUN_GN_FWD(S_, C_) \
+  hipLaunchKernelGGL((k_gn_fwd<S_, C_>), dim3(N * G), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_rstd, C, HW, G, (float)eps)
+  if (silu && cached) SALUN_GN_FWD(true, true);
+  else if (silu) SALUN_GN_FWD(true, false);
+  else if (cached) SALUN_GN_FWD(false, true);
+  else SALUN_GN_FWD(false, false);
+#undef SALUN_GN_FWD
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+// dx, dgamma, dbeta of  z = [silu](GroupNorm(x))  given dz; y and sigma(y) are recomputed from x.
+SALUN_EXPORT int salun_gn_backward(const float *dz, const float *x, const float *gamma, const float *beta,
+                                   const float *save_mean, const float *save_rstd, float *dx, float *dgamma,
+                                   float *dbeta, float *grad_gamma_acc, float *grad_beta_acc, int N, int C, int HW,
+                                   int G, int silu, void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (!dz || !x || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !gn_shape_ok(N, C, HW, G))
+    return SALUN_EINVAL;
+  if (!ws || ws_bytes < salun_gn_workspace_bytes(N, C)) return SALUN_ENOSPC;
+  if (!salun_aligned16(dz) || !salun_aligned16(x) || !salun_aligned16(dx)) return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  float *pg = static_cast<float *>(ws), *pb = pg + (size_t)N * C;
+  const bool cached = (int64_t)(C / G) * HW / 4 <= (int64_t)GN_ITEMS * 256;
+#define SALUN_GN_BWD(S_, C_) \
+  hipLaunchKernelGGL((k_gn_bwd<S_, C_>), dim3(N * G), dim3(256), 0, st, dz, x, gamma, beta, save_mean, save_rstd, dx, pg, pb, C, HW, G)
+  if (silu && cached) SALUN_GN_BWD(true, true);
+  else if (silu) SALUN_GN_BWD(true, false);
+  else if (cached) SALUN_GN_BWD(false, true);
+  else SALUN_GN_BWD(false, false);
+#undef SALUN_GN_BWD
+  SALUN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, pg, pb, N, C, dgamma, dbeta,
+                     grad_gamma_acc, grad_beta_acc);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}

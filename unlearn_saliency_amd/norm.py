@@ -63,6 +63,54 @@ def fused_bn_act(x: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor = N
                           bn.momentum, bn.eps, relu)
 
 
+class _FusedGN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, silu):
+        out = ops.gn_forward(x, weight, bias, groups, eps, silu)
+        if out is None:
+            raise RuntimeError("fused GroupNorm: unsupported shape")
+        z, mean, rstd = out
+        ctx.save_for_backward(x, weight, bias, mean, rstd)  # y and sigmoid(y) are recomputed in backward
+        ctx.cfg = (int(groups), bool(silu))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        groups, silu = ctx.cfg
+        gw, gb = gradsink.sink(weight), gradsink.sink(bias)
+        if gw is None or gb is None:
+            gw = gb = None
+        dx, dgamma, dbeta = ops.gn_backward(dz.contiguous(), x, weight, bias, mean, rstd, groups, silu, gw, gb)
+        if gw is not None:
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, None, None, None
+
+
+_FUSED_GN = True
+
+
+def enable_fused_gn(flag: bool) -> None:
+    """Process-wide switch of `fused_gn_act` (on by default; off = the library's group_norm + sigmoid + mul)."""
+    global _FUSED_GN
+    _FUSED_GN = bool(flag)
+
+
+def fused_gn_act(x: torch.Tensor, gn: nn.GroupNorm, silu: bool = True) -> torch.Tensor:
+    """`[x * sigmoid(x)](gn(x))` — one forward and two backward launches on csrc/salun_norm.hip for fp32 NCHW device
+    tensors whose H*W is a power of two; anything else runs the library ops."""
+    hw = x.shape[2] * x.shape[3] if x.dim() == 4 else 0
+    if (_FUSED_GN and type(gn) in _GN_TYPES and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and gn.affine and hw >= 4 and (hw & (hw - 1)) == 0 and x.shape[1] // gn.num_groups <= 256
+            and not torch.is_autocast_enabled()):
+        return _FusedGN.apply(x.contiguous(), gn.weight, gn.bias, gn.num_groups, gn.eps, silu)
+    y = gn(x)
+    return y * torch.sigmoid(y) if silu else y
+
+
+_GN_TYPES = {nn.GroupNorm}
+
+
 def use_fused_bn(model: nn.Module, blocks: bool = True) -> int:
     """Switch this package's CIFAR ResNet (stem + BasicBlocks) to the fused BN path; with `blocks` each BasicBlock
     additionally runs as one autograd node (resblock.py).  Returns the number of BatchNorm layers covered."""

@@ -308,6 +308,42 @@ def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, want_dres, gamma_
     return dx, dres, dgamma, dbeta
 
 
+# ------------------------------------------------------------------- fused GroupNorm
+def gn_forward(x, gamma, beta, groups, eps, silu):
+    """-> (z, save_mean, save_rstd) or None when the shape is outside the kernel's domain."""
+    N, C, H, W = x.shape
+    z = torch.empty_like(x)
+    mean = torch.empty(N * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(N * groups, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().salun_gn_forward(_dev(x, torch.float32, "x"), c_void_p(z.data_ptr()),
+                                     _dev(gamma, torch.float32, "weight"), _dev(beta, torch.float32, "bias"),
+                                     c_void_p(mean.data_ptr()), c_void_p(rstd.data_ptr()), N, C, H * W, int(groups),
+                                     c_double(eps), int(bool(silu)), _stream())
+    if rc == _lib.SALUN_EINVAL:
+        return None
+    check(rc, "salun_gn_forward")
+    return z, mean, rstd
+
+
+def gn_backward(dz, x, gamma, beta, mean, rstd, groups, silu, gamma_grad_acc=None, beta_grad_acc=None):
+    """-> (dx, dgamma, dbeta)."""
+    N, C, H, W = x.shape
+    L = _lib.lib()
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(L.salun_gn_workspace_bytes(N, C), x.device)
+    check(L.salun_gn_backward(_dev(dz, torch.float32, "dz"), _dev(x, torch.float32, "x"),
+                              _dev(gamma, torch.float32, "weight"), _dev(beta, torch.float32, "bias"),
+                              _dev(mean, torch.float32, "mean"), _dev(rstd, torch.float32, "rstd"),
+                              c_void_p(dx.data_ptr()), c_void_p(dgamma.data_ptr()), c_void_p(dbeta.data_ptr()),
+                              _dev(gamma_grad_acc, torch.float32, "weight.grad", True),
+                              _dev(beta_grad_acc, torch.float32, "bias.grad", True), N, C, H * W, int(groups),
+                              int(bool(silu)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()),
+          "salun_gn_backward")
+    return dx, dgamma, dbeta
+
+
 # ------------------------------------------------------------------------ K9 / K10
 def proximal_step(p: torch.Tensor, p0: torch.Tensor, ratio: int, scratch: Optional[torch.Tensor] = None,
                   scratch_mask: Optional[torch.Tensor] = None) -> torch.Tensor:

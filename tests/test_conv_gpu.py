@@ -29,6 +29,8 @@ SHAPES = [
     (8, 3, 32, 64, 3, 2, 1),      # small-C backward-weight kernel, stride 2
     (5, 1, 16, 40, 3, 1, 1),      # single input channel, ragged N and K
     (6, 4, 64, 320, 3, 1, 1),     # SD conv_in (C = 4 latents)
+    (2, 320, 32, 320, 3, 1, 1),   # SD: K = 320 is not a multiple of the 128-channel tile (ragged block, fast staging)
+    (2, 64, 16, 200, 1, 1, 0),    # ragged K, 1x1
 ]
 
 

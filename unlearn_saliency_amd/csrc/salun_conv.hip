@@ -167,8 +167,10 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
         const int e4 = tid + i * 256;
         if (NF4 % 256 == 0 || e4 < NF4) {
           const int row = e4 / ROWF4, q4 = e4 - row * ROWF4;
+          // forward: a ragged last channel block re-reads the last real row (its results are masked in the epilogue)
+          const int krow = (k0 + row < wK) ? k0 + row : wK - 1;
           const float *src = DGRAD ? (w + (size_t)(c0 + row) * wC * RS + (size_t)k0 * RS + 4 * q4)
-                                   : (w + (size_t)(k0 + row) * wC * RS + (size_t)c0 * RS + 4 * q4);
+                                   : (w + (size_t)krow * wC * RS + (size_t)c0 * RS + 4 * q4);
           wreg4[i] = *reinterpret_cast<const float4 *>(src);
         }
       }
@@ -921,8 +923,8 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
     const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));                  \
     dim3 grid(g.ntiles, (yC + KB - 1) / KB);                                                                    \
     /* FAST staging: full reduction chunks, channel tile inside the tensor, float4-aligned weight runs */      \
-    const bool fast = (xC % CC == 0) && (yC % KB == 0) && salun_aligned16(w) && ((wC * RS) % 4 == 0) &&         \
-                      !(DGRAD && STRIDE > 1);                                                                   \
+    const bool fast = (xC % CC == 0) && (!DGRAD || yC % KB == 0) && salun_aligned16(w) &&                       \
+                      ((wC * RS) % 4 == 0) && !(DGRAD && STRIDE > 1);                                           \
     if (fast) {                                                                                                 \
       allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>, ldsb);                                       \
       hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>), grid, dim3(256), ldsb, st, x, w,  \

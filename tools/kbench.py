@@ -75,11 +75,65 @@ def run(n, iters, nk_list=(1, 10)):
     return res
 
 
+def run_norm(iters):
+    """Fused BatchNorm / GroupNorm kernels at the activation shapes of the benchmarks; bytes = algorithmic traffic
+    per activation element (fp32 tensors read/written once per pass that needs them)."""
+    res = {}
+
+    def rec(name, sec, nbytes):
+        gbs = nbytes / sec / 1e9
+        res[name] = {"us": sec * 1e6, "alg_bytes": nbytes, "GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
+        print(f"  {name:44s} {sec*1e6:10.1f} us  {gbs:8.1f} GB/s  ({gbs/HBM_PEAK_GBS:.3f} of 8 TB/s)", flush=True)
+
+    for tag, shape in (("resnet l1 256x64x32x32", (256, 64, 32, 32)), ("resnet l4 256x512x4x4", (256, 512, 4, 4))):
+        N, C, H, W = shape
+        x = torch.randn(shape, device="cuda"); r = torch.randn(shape, device="cuda"); dy = torch.randn(shape, device="cuda")
+        g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+        rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda")
+        e = x.numel() * 4
+        y, m, i = ops.bn_forward(x, r, g, b, rm, rv, True, 0.1, 1e-5, True)
+        # forward: stats read x; apply reads x, res, writes y
+        rec(f"bn_forward+res+relu {tag} (16B)", timeit(lambda: ops.bn_forward(x, r, g, b, rm, rv, True, 0.1, 1e-5, True), iters), 4 * e)
+        # backward: reduce reads dy, y, x; apply reads dy, y, x, writes dx, dres
+        rec(f"bn_backward+dres {tag} (32B)", timeit(lambda: ops.bn_backward(dy, y, x, g, m, i, True, True, True), iters), 8 * e)
+    for tag, shape in (("ddpm 128x128x32x32", (128, 128, 32, 32)), ("ddpm 128x256x16x16", (128, 256, 16, 16)),
+                       ("sd 8x320x64x64", (8, 320, 64, 64))):
+        N, C, H, W = shape
+        x = torch.randn(shape, device="cuda"); dz = torch.randn(shape, device="cuda")
+        g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+        e = x.numel() * 4
+        z, m, rs = ops.gn_forward(x, g, b, 32, 1e-6, True)
+        rec(f"gn_forward+silu {tag} (8B)", timeit(lambda: ops.gn_forward(x, g, b, 32, 1e-6, True), iters), 2 * e)
+        rec(f"gn_backward+silu {tag} (12B)", timeit(lambda: ops.gn_backward(dz, x, g, b, m, rs, 32, True), iters), 3 * e)
+    return res
+
+
+def run_next(n, iters):
+    """K9 / K10 on flat vectors of n elements."""
+    res = {}
+    p0 = ops.fill_normal(n, 1, 0, 0.05)
+    p = p0 + ops.fill_normal(n, 2, 0, 0.01)
+    F = ops.fill_uniform(n, 3, 0.0, 50.0)
+    g = ops.fill_normal(n, 4, 0, 1e-3)
+    scratch = torch.empty_like(p); sm = torch.empty(n, dtype=torch.uint8, device="cuda")
+
+    def rec(name, sec, bpe):
+        gbs = bpe * n / sec / 1e9
+        res[name] = {"us": sec * 1e6, "alg_bytes_per_elem": bpe, "GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
+        print(f"  {name:44s} {sec*1e6:10.1f} us  {gbs:8.1f} GB/s  ({gbs/HBM_PEAK_GBS:.3f} of 8 TB/s)", flush=True)
+
+    rec("ewc_penalty_grad(20B)", timeit(lambda: ops.ewc_penalty_grad(p, p0, F, g, 10.0), iters), 20)
+    q = p.clone()
+    rec("proximal_step(diff+select+soft, 24B)", timeit(lambda: ops.proximal_step(q, p0, n // 4, scratch, sm), max(iters // 5, 3)), 24)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="n18,nd")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--extra", action="store_true", help="also time the fused norm kernels and K9/K10")
     a = ap.parse_args()
     out = {}
     for s in a.sizes.split(","):
@@ -87,6 +141,13 @@ def main():
         print(f"== {s}: N = {n:,}", flush=True)
         out[s] = run(n, a.iters if s != "ns" else max(a.iters // 5, 3))
         torch.cuda.empty_cache()
+    if a.extra:
+        print("== fused norm kernels", flush=True)
+        out["norm"] = run_norm(a.iters)
+        print(f"== next rows at N18", flush=True)
+        out["next_n18"] = run_next(SIZES["n18"], a.iters)
+        print(f"== next rows at N_D", flush=True)
+        out["next_nd"] = run_next(SIZES["nd"], a.iters)
     if a.json:
         os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
         with open(a.json, "w") as f:

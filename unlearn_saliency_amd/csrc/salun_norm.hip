@@ -324,7 +324,7 @@ SALUN_EXPORT int salun_bn_backward(const float *dy, const float *y, const float 
 // group sums of the input gradient, and writes dx — x and dz are read once.
 namespace {
 
-constexpr int GN_ITEMS = 16;            // float4 per lane held in registers (cached mode)
+constexpr int GN_ITEMS = 16;            // most float4 per lane held in registers (ITEMS = 1, 2, 4, 8, 16; 0 = re-read mode)
 constexpr int GN_MAX_SEG = 1024;        // LDS slots for segment sums
 
 __device__ __forceinline__ float gn_sigmoid(float y) { return 1.0f / (1.0f + expf(-y)); }
@@ -335,11 +335,12 @@ __device__ __forceinline__ float seg_sum(float v, int r) {
   return v;
 }
 
-template <bool SILU, bool CACHED>
+template <bool SILU, int ITEMS>
 __global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, float *__restrict__ y,
                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                 float *__restrict__ mean, float *__restrict__ rstd, int C, int HW,
                                                 int G, float eps) {
+  constexpr bool CACHED = ITEMS > 0;
   __shared__ double lds[4];
   __shared__ float st[2];
   const int ng = blockIdx.x, n = ng / G, g = ng - n * G;
@@ -347,12 +348,12 @@ __global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, flo
   const int L = cpg * HW, nvec = L >> 2;
   const size_t base = ((size_t)n * C + (size_t)g * cpg) * HW;
   const float4 *xv = reinterpret_cast<const float4 *>(x + base);
-  float4 v[CACHED ? GN_ITEMS : 1];
+  float4 v[CACHED ? ITEMS : 1];
   float s1 = 0.f, s2 = 0.f;
   double d1 = 0.0, d2 = 0.0;
   if (CACHED) {
 #pragma unroll
-    for (int i = 0; i < GN_ITEMS; ++i) {
+    for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {
       const int e = threadIdx.x + i * 256;
       if (e < nvec) {
         v[i] = xv[e];
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, flo
   };
   if (CACHED) {
 #pragma unroll
-    for (int i = 0; i < GN_ITEMS; ++i) {
+    for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {
       const int e = threadIdx.x + i * 256;
       if (e < nvec) apply(e, v[i]);
     }
@@ -411,12 +412,13 @@ __global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, flo
 
 // Backward.  seg: aligned run of r = min(HW/4, 64) lanes inside one channel; segment sums go to LDS, channel sums
 // are folded from them by one lane per channel, group sums from the channel sums — all in fixed order.
-template <bool SILU, bool CACHED>
+template <bool SILU, int ITEMS>
 __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, const float *__restrict__ x,
                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                 float *__restrict__ dx, float *__restrict__ part_dgamma,
                                                 float *__restrict__ part_dbeta, int C, int HW, int G) {
+  constexpr bool CACHED = ITEMS > 0;
   __shared__ float seg_g[GN_MAX_SEG], seg_b[GN_MAX_SEG];
   __shared__ float grp[2];
   const int ng = blockIdx.x, n = ng / G, g = ng - n * G;
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
   const float mu = mean[ng], rs = rstd[ng];
   const int r = hw4 < 64 ? hw4 : 64;          // lanes per segment (power of two)
   const int segs_per_ch = hw4 / r;            // >= 1
-  float4 xc[CACHED ? GN_ITEMS : 1], dc[CACHED ? GN_ITEMS : 1];
+  float4 xc[CACHED ? ITEMS : 1], dc[CACHED ? ITEMS : 1];
 
   // dy (gradient w.r.t. the normalised, affine output) of one float4, from x and dz
   auto dy_of = [&](int e, float4 xt, float4 gt, float4 &xh) {
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
   const int nround = (nvec + 255) / 256;  // every lane walks the same number of rounds (shuffles need all lanes)
   if (CACHED) {
 #pragma unroll
-    for (int i = 0; i < GN_ITEMS; ++i) {
+    for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {
       if (i < nround) {
         const int e = threadIdx.x + i * 256;
         const bool valid = e < nvec;
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
   };
   if (CACHED) {
 #pragma unroll
-    for (int i = 0; i < GN_ITEMS; ++i) {
+    for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {
       const int e = threadIdx.x + i * 256;
       if (e < nvec) emit(e, xc[i], dc[i]);
     }
@@ -549,6 +551,14 @@ __global__ __launch_bounds__(256) void k_gn_bwd_final(const float *__restrict__ 
   if (bacc) bacc[c] += (float)sb;
 }
 
+// float4 per lane kept in registers: the smallest of 1, 2, 4, 8, 16 covering the group; 0 = too large, re-read mode
+inline int gn_items(int C, int HW, int G) {
+  const int64_t nvec = (int64_t)(C / G) * HW / 4;
+  for (int it = 1; it <= GN_ITEMS; it <<= 1)
+    if (nvec <= (int64_t)it * 256) return it;
+  return 0;
+}
+
 inline bool gn_shape_ok(int N, int C, int HW, int G) {
   if (N < 1 || C < 1 || G < 1 || C % G != 0 || HW < 4 || (HW & (HW - 1)) != 0) return false;  // HW: power of two >= 4
   const int cpg = C / G;
@@ -570,13 +580,20 @@ SALUN_EXPORT int salun_gn_forward(const float *x, float *y, const float *gamma, 
   if (!x || !y || !gamma || !beta || !save_mean || !save_rstd || !gn_shape_ok(N, C, HW, G)) return SALUN_EINVAL;
   if (!salun_aligned16(x) || !salun_aligned16(y)) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
-  const bool cached = (int64_t)(C / G) * HW / 4 <= (int64_t)GN_ITEMS * 256;
-#define SALUN_GN_FWD(S_, C_) \
-  hipLaunchKernelGGL((k_gn_fwd<S_, C_>), dim3(N * G), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_rstd, C, HW, G, (float)eps)
-  if (silu && cached) SALUN_GN_FWD(true, true);
-  else if (silu) SALUN_GN_FWD(true, false);
-  else if (cached) SALUN_GN_FWD(false, true);
-  else SALUN_GN_FWD(false, false);
+  const int items = gn_items(C, HW, G);
+#define SALUN_GN_FWD(S_, I_) \
+  hipLaunchKernelGGL((k_gn_fwd<S_, I_>), dim3(N * G), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_rstd, C, HW, G, (float)eps)
+#define SALUN_GN_FWD_I(S_)                    \
+  switch (items) {                            \
+    case 1: SALUN_GN_FWD(S_, 1); break;       \
+    case 2: SALUN_GN_FWD(S_, 2); break;       \
+    case 4: SALUN_GN_FWD(S_, 4); break;       \
+    case 8: SALUN_GN_FWD(S_, 8); break;       \
+    case 16: SALUN_GN_FWD(S_, 16); break;     \
+    default: SALUN_GN_FWD(S_, 0); break;      \
+  }
+  if (silu) { SALUN_GN_FWD_I(true) } else { SALUN_GN_FWD_I(false) }
+#undef SALUN_GN_FWD_I
 #undef SALUN_GN_FWD
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
@@ -593,13 +610,20 @@ SALUN_EXPORT int salun_gn_backward(const float *dz, const float *x, const float 
   if (!salun_aligned16(dz) || !salun_aligned16(x) || !salun_aligned16(dx)) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
   float *pg = static_cast<float *>(ws), *pb = pg + (size_t)N * C;
-  const bool cached = (int64_t)(C / G) * HW / 4 <= (int64_t)GN_ITEMS * 256;
-#define SALUN_GN_BWD(S_, C_) \
-  hipLaunchKernelGGL((k_gn_bwd<S_, C_>), dim3(N * G), dim3(256), 0, st, dz, x, gamma, beta, save_mean, save_rstd, dx, pg, pb, C, HW, G)
-  if (silu && cached) SALUN_GN_BWD(true, true);
-  else if (silu) SALUN_GN_BWD(true, false);
-  else if (cached) SALUN_GN_BWD(false, true);
-  else SALUN_GN_BWD(false, false);
+  const int items = gn_items(C, HW, G);
+#define SALUN_GN_BWD(S_, I_) \
+  hipLaunchKernelGGL((k_gn_bwd<S_, I_>), dim3(N * G), dim3(256), 0, st, dz, x, gamma, beta, save_mean, save_rstd, dx, pg, pb, C, HW, G)
+#define SALUN_GN_BWD_I(S_)                    \
+  switch (items) {                            \
+    case 1: SALUN_GN_BWD(S_, 1); break;       \
+    case 2: SALUN_GN_BWD(S_, 2); break;       \
+    case 4: SALUN_GN_BWD(S_, 4); break;       \
+    case 8: SALUN_GN_BWD(S_, 8); break;       \
+    case 16: SALUN_GN_BWD(S_, 16); break;     \
+    default: SALUN_GN_BWD(S_, 0); break;      \
+  }
+  if (silu) { SALUN_GN_BWD_I(true) } else { SALUN_GN_BWD_I(false) }
+#undef SALUN_GN_BWD_I
 #undef SALUN_GN_BWD
   SALUN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, pg, pb, N, C, dgamma, dbeta,

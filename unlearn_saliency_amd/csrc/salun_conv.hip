@@ -503,6 +503,201 @@ __global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// backward-data of a STRIDE-2 convolution, all four output parities in one launch.
+//   dx[2a+ph][2b+pw] = sum_k sum_{r = (ph+PAD) mod 2 (+2), s likewise} w[k][c][r][s] * dy[k][a + d(r)][b + d(s)],
+//   d(r) = (ph + PAD - r) / 2  in {-1, 0, 1}
+// A workgroup owns a tile of sub-grid pixels (a, b) and 32*KT*WK channels; every wave keeps 4*KT accumulators (one
+// per parity class and channel tile).  The dY patch (tile rows + one halo row/column) and the full R*R weight slab of
+// a reduction chunk are staged once and serve all classes — same MFMA count as the forward pass, no zero
+// insertion, one launch instead of four, and the epilogue writes (2b, 2b+1) pairs: full coalesced rows of dX.
+// (The per-class conv_igemm_tap path stays as the fallback for shapes outside this kernel's staging assumptions.)
+template <int R, int PAD, int KT, int WP, int WK>
+__global__ __launch_bounds__(256) void conv_dgrad_s2(const float *__restrict__ dy, const float *__restrict__ w,
+                                                     const float *__restrict__ addend, float *__restrict__ dx, int N,
+                                                     int K, int P, int Q, int C, int H, int W, int NI, int TP,
+                                                     int IH_t, int IW_t, int logQ) {
+  constexpr int RS = R * R;
+  constexpr int KB = WK * KT * 32;
+  constexpr int WROW = CC * RS + 1;
+  constexpr int DMIN = (R == 1) ? 0 : (PAD == 1 ? 0 : -1);  // smallest row/column offset d(r) that occurs
+  constexpr int FP = (R == 1) ? 1 : 2;                      // patch footprint per dimension
+  constexpr int NCLS = (R == 1) ? 1 : 4;                    // parity classes that receive any tap
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int PSZ = NI * IH_t * IW_t;
+  const int ch_stride = PSZ | 1;
+  float *patch = lds;                // [CC][ch_stride]
+  float *wl = lds + CC * ch_stride;  // [KB][WROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wp = wave % WP, wk = wave / WP;
+  const int tiles_per_img = (NI > 1) ? 1 : P / TP;
+  const int tile = blockIdx.x;
+  const int c0out = blockIdx.y * KB;  // first dX channel of this workgroup
+  int n0, p0;
+  if (NI > 1) { n0 = tile * NI; p0 = 0; }
+  else { n0 = tile / tiles_per_img; p0 = (tile - n0 * tiles_per_img) * TP; }
+
+  const int mloc = wp * 32 + lo;
+  const int q_l = mloc & (Q - 1);
+  const int pr = mloc >> logQ;
+  const int ni_l = pr / TP, p_l = pr - ni_l * TP;
+  const int pix_off = (ni_l * IH_t + p_l) * IW_t + q_l;  // patch position of offset (DMIN, DMIN)
+
+  // the one patch position this thread stages per reduction channel (PSZ <= 256)
+  const int planePQ = P * Q;
+  int goff = 0;
+  bool valid = false;
+  if (tid < PSZ) {
+    const int ni = tid / (IH_t * IW_t);
+    const int rem = tid - ni * (IH_t * IW_t);
+    const int ih = rem / IW_t, iw = rem - ih * IW_t;
+    const int n = n0 + ni;
+    const int pp = p0 + DMIN + ih, qq = DMIN + iw;
+    valid = (n < N) && pp >= 0 && pp < P && qq >= 0 && qq < Q;
+    goff = valid ? (n * K * planePQ + pp * Q + qq) : 0;
+  }
+
+  f32x16 acc[NCLS][KT];
+#pragma unroll
+  for (int cl = 0; cl < NCLS; ++cl)
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[cl][t][v] = 0.f;
+
+  constexpr int ROWF4 = KB * RS / 4;  // float4 per contiguous run of one reduction row: (c in block, r, s)
+  constexpr int NF4 = CC * ROWF4;
+  constexpr int WN4 = (NF4 + 255) / 256;
+  float preg[CC];
+  float4 wreg4[WN4];
+  auto load_chunk = [&](int k0) {
+    if (valid) {
+      const float *src = dy + goff + k0 * planePQ;
+#pragma unroll
+      for (int c = 0; c < CC; ++c) preg[c] = src[c * planePQ];
+    } else {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) preg[c] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < WN4; ++i) {
+      const int e4 = tid + i * 256;
+      if (NF4 % 256 == 0 || e4 < NF4) {
+        const int row = e4 / ROWF4, q4 = e4 - row * ROWF4;
+        wreg4[i] = *reinterpret_cast<const float4 *>(w + (size_t)(k0 + row) * C * RS + (size_t)c0out * RS + 4 * q4);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+    if (tid < PSZ) {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) patch[c * ch_stride + tid] = preg[c];
+    }
+#pragma unroll
+    for (int i = 0; i < WN4; ++i) {
+      const int e4 = tid + i * 256;
+      if (NF4 % 256 == 0 || e4 < NF4) {
+        const int row = e4 / ROWF4, q4 = e4 - row * ROWF4;
+        const float v4[4] = {wreg4[i].x, wreg4[i].y, wreg4[i].z, wreg4[i].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = 4 * q4 + u;  // position in the (c, rs) run of reduction row `row`
+          const int cl = idx / RS, rs = idx - cl * RS;
+          wl[cl * WROW + row * RS + rs] = v4[u];
+        }
+      }
+    }
+  };
+
+  load_chunk(0);
+  for (int k0 = 0; k0 < K; k0 += CC) {
+    __syncthreads();
+    store_chunk();
+    __syncthreads();
+    if (k0 + CC < K) load_chunk(k0 + CC);
+    constexpr int NSTEP = CC / 2;
+    const float *pb0 = patch + hi * ch_stride + pix_off;
+    const float *wb0 = wl + (wk * KT * 32 + lo) * WROW + hi * RS;
+    // operands of reduction pair `step`: the FP*FP patch values around this lane's pixel and the R*R*KT weights
+    auto operands = [&](int step, float (&bv)[FP * FP], float (&av)[KT][RS]) {
+      const int cc = 2 * step;
+#pragma unroll
+      for (int di = 0; di < FP; ++di)
+#pragma unroll
+        for (int dj = 0; dj < FP; ++dj) bv[di * FP + dj] = pb0[cc * ch_stride + di * IW_t + dj];
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int rs = 0; rs < RS; ++rs) av[t][rs] = wb0[t * 32 * WROW + cc * RS + rs];
+    };
+    float b_cur[FP * FP], a_cur[KT][RS], b_nxt[FP * FP], a_nxt[KT][RS];
+    operands(0, b_cur, a_cur);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + 1 < NSTEP) operands(step + 1, b_nxt, a_nxt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < R; ++s2) {
+          // tap (r, s2) feeds parity class (ph, pw) from the patch value at offsets (d(r), d(s2))
+          const int ph = (R == 1) ? 0 : ((r - PAD) & 1), pw = (R == 1) ? 0 : ((s2 - PAD) & 1);
+          const int di = (R == 1) ? 0 : ((ph + PAD - r) / 2 - DMIN), dj = (R == 1) ? 0 : ((pw + PAD - s2) / 2 - DMIN);
+          const int cls = (R == 1) ? 0 : (ph * 2 + pw);
+#pragma unroll
+          for (int t = 0; t < KT; ++t)
+            acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t][r * R + s2], b_cur[di * FP + dj], acc[cls][t],
+                                                               0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (step + 1 < NSTEP) {
+#pragma unroll
+        for (int i = 0; i < FP * FP; ++i) b_cur[i] = b_nxt[i];
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int rs = 0; rs < RS; ++rs) a_cur[t][rs] = a_nxt[t][rs];
+      }
+    }
+  }
+
+  // ---- epilogue: lane = sub-pixel (a, b); rows 2a, 2a+1; each store is the (2b, 2b+1) pair
+  const int n_out = n0 + ni_l;
+  const int a_out = p0 + p_l;
+  if (n_out < N) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int cbase = c0out + (wk * KT + t) * 32;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int c = cbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
+        if (c < C) {
+#pragma unroll
+          for (int ph = 0; ph < 2; ++ph) {
+            const size_t oi = (((size_t)n_out * C + c) * H + (2 * a_out + ph)) * W + 2 * q_l;
+            float2 o;
+            if (R == 1) {
+              o.x = (ph == 0) ? acc[0][t][v] : 0.f;
+              o.y = 0.f;
+            } else {
+              o.x = acc[ph * 2 + 0][t][v];
+              o.y = acc[ph * 2 + 1][t][v];
+            }
+            if (addend) {
+              const float2 ad = *reinterpret_cast<const float2 *>(addend + oi);
+              o.x += ad.x;
+              o.y += ad.y;
+            }
+            *reinterpret_cast<float2 *>(dx + oi) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward-weight.  Workgroup: 4 waves = 2 k-tiles x 2 c-tiles of 32; each wave keeps RS accumulators (one per
 // filter tap), so a 64-pixel chunk of x / dy staged in LDS feeds R*R MFMAs per pixel pair.
 // grid = (K/64 rounded up, C/64 rounded up, nsplit); split s handles pixel chunks s, s+nsplit, ...
@@ -1003,6 +1198,52 @@ int launch_igemm_tap(IgemmArgs a, hipStream_t st) {
   return SALUN_OK;
 }
 
+// stride-2 backward-data, all parity classes in one launch (conv_dgrad_s2).  SALUN_EINVAL = not applicable.
+template <int R>
+int launch_dgrad_s2_merged(const float *dy, const float *w, const float *addend, float *dx, int N, int C, int H, int W,
+                           int K, int pad, int P, int Q, hipStream_t st) {
+  if (H != 2 * P || W != 2 * Q) return SALUN_EINVAL;
+  if (!((R == 3 && (pad == 0 || pad == 1)) || (R == 1 && pad == 0))) return SALUN_EINVAL;
+  constexpr int RS = R * R;
+  if (K % CC != 0 || !salun_aligned16(w) || (C * RS) % 4 != 0) return SALUN_EINVAL;
+  if (!salun_aligned16(dx) || (addend && !salun_aligned16(addend))) return SALUN_EINVAL;  // float2 row pairs
+  // tiles of sub-grid pixels; channel tile 64 or 128 (4*KT accumulators per wave: KT <= 2)
+  const int fp = (R == 1) ? 1 : 2;
+  int pixt = 128;
+  TileGeom g = make_geom(N, P, Q, pixt, 1, fp);
+  const int cb64 = (C + 63) / 64;
+  if (!g.ok || g.ntiles * cb64 < 256) {
+    TileGeom g64 = make_geom(N, P, Q, 64, 1, fp);
+    if (g64.ok) { g = g64; pixt = 64; }
+  }
+  if (!g.ok || g.NI * g.IH_t * g.IW_t > 256) return SALUN_EINVAL;
+  const int PSZ = g.NI * g.IH_t * g.IW_t;
+  const int ch_stride = PSZ | 1;
+#define SALUN_DGS2(PAD_, KT_, WP_, WK_)                                                                          \
+  {                                                                                                              \
+    constexpr int KB = WK_ * KT_ * 32;                                                                           \
+    if (C % KB != 0) return SALUN_EINVAL;                                                                        \
+    const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));                   \
+    dim3 grid(g.ntiles, C / KB);                                                                                 \
+    allow_lds(conv_dgrad_s2<R, PAD_, KT_, WP_, WK_>, ldsb);                                                      \
+    hipLaunchKernelGGL((conv_dgrad_s2<R, PAD_, KT_, WP_, WK_>), grid, dim3(256), ldsb, st, dy, w, addend, dx, N, \
+                       K, P, Q, C, H, W, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ);                                    \
+  }
+#define SALUN_DGS2_TILES(PAD_)                                                               \
+  if (pixt == 128) {                                                                         \
+    if (C % 64 == 0) SALUN_DGS2(PAD_, 2, 4, 1)                                               \
+    else SALUN_DGS2(PAD_, 1, 4, 1)                                                           \
+  } else {                                                                                   \
+    if (C % 128 == 0 && g.ntiles * (C / 128) >= 256) SALUN_DGS2(PAD_, 2, 2, 2)               \
+    else SALUN_DGS2(PAD_, 1, 2, 2)                                                           \
+  }
+  if (pad == 1) { SALUN_DGS2_TILES(1) } else { SALUN_DGS2_TILES(0) }
+#undef SALUN_DGS2_TILES
+#undef SALUN_DGS2
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
 // backward-data: one launch for stride 1, one launch per output parity class for stride 2
 template <int R>
 int launch_dgrad(const float *dy, const float *w, const float *addend, float *dx, int N, int C, int H, int W, int K,
@@ -1017,6 +1258,10 @@ int launch_dgrad(const float *dy, const float *w, const float *addend, float *dx
     return launch_igemm<R, 1, true>(dy, w, addend, dx, N, K, P, Q, C, H, W, pad, C, K, st);
   }
   if ((H & 1) || (W & 1)) return SALUN_EINVAL;
+  {
+    const int rc = launch_dgrad_s2_merged<R>(dy, w, addend, dx, N, C, H, W, K, pad, P, Q, st);
+    if (rc != SALUN_EINVAL) return rc;  // SALUN_EINVAL: outside the merged kernel's domain -> per-class path below
+  }
   a.subH = H / 2; a.subW = W / 2; a.os = 2; a.ts = 2;
   // taps of parity class p: r = (p + pad) mod 2, +2, ... < R ; rtop = the largest
   int ntap[2], rtop[2];

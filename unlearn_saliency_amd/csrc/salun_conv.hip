@@ -9,17 +9,23 @@
 // Layouts are the reference's: activations NCHW, weights OIHW read straight from the flat parameter arena.
 //
 // Forward / backward-data (one kernel, `conv_igemm`): D[k][pix] = sum_{c,r,s} Wt[k][c,r,s] * X[c][pix + (r,s)]
-//   * workgroup = 256 threads = 4 waves; tile = PIXT (64|128) output pixels x KB (32..128) output channels;
+//   * workgroup = 256 threads = 4 waves; tile = 64|128 output pixels x KB (32..128) output channels;
 //     A operand = weights (rows = output channels), B operand = input pixels, so a wave's 32 result columns are 32
 //     consecutive pixels and the NCHW store is coalesced;
 //   * per chunk of CC=8 reduction channels the input *patch* (tile rows + halo, zero padded) and the weight slab
 //     are staged in LDS once; the R*S taps are addressed inside the patch (no im2col copy), one ds_read_b32 per
 //     operand per MFMA, bank-conflict-free (odd row strides);
-//   * backward-data is the same loop over the (zero-upsampled for stride 2) output gradient with the weight
-//     slab transposed and tap-flipped while it is staged.
+//   * backward-data of a stride-1 convolution is the same loop over dY with the weight slab transposed and
+//     tap-flipped while it is staged; an optional full-size addend (the residual branch's gradient) rides in the
+//     epilogue.
+// Backward-data, stride 2 (`conv_dgrad_s2`): all four output parities in one launch — shared dY patch, one
+//   accumulator per (parity, channel tile), exact FLOPs (no zero insertion), paired row stores; the per-parity
+//   `conv_igemm_tap` launches remain as the fallback for shapes outside its staging assumptions.
 // Backward-weight (`conv_wgrad`): dW[k][c][r,s] = sum_pix dY[k][pix] * X[c][pix + (r,s)]: reduction over pixels,
 //   9 accumulators (one per tap) per wave, pixel range split over workgroups -> partials -> fixed-order reduce
-//   (deterministic, no float atomics).
+//   (deterministic, no float atomics); staging interleaved between the MFMAs (see the kernel).  `conv_wgrad_smallc`
+//   serves C*R*R <= 32 (the RGB stem) with the (c,r,s) combinations as the MFMA columns.
+// Ceilings (tools/micro/mfma_peak.hip): 155.6 TFLOP/s register operands, 144 with this file's LDS operand pattern.
 #include "salun_common.h"
 #include <mutex>
 #include <unordered_set>
@@ -69,7 +75,6 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
                                                   int TP, int IH_t, int IW_t, int logQ, int wC /*w dim1 (C of OIHW)*/,
                                                   int wK /*w dim0*/) {
   constexpr int RS = R * R;
-  constexpr int PIXT = WP * 32;        // pixels per workgroup tile
   constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
   constexpr int WROW = CC * RS + 1;    // LDS weight row (odd => conflict-free across 32 rows)
   constexpr int CONV_S = DGRAD ? 1 : STRIDE;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, c
   else { n0 = tile / tiles_per_img; p0 = (tile - n0 * tiles_per_img) * TP; }
 
   // ---- this lane's output pixel inside the tile (fixed for the whole kernel)
-  const int mloc = wp * 32 + lo;               // 0..PIXT-1
+  const int mloc = wp * 32 + lo;               // 0 .. WP*32-1: pixel inside the workgroup tile
   const int q_l = mloc & (Q - 1);
   const int pr = mloc >> logQ;                 // row index inside the tile (over NI*TP rows)
   const int ni_l = pr / TP, p_l = pr - ni_l * TP;
@@ -862,7 +867,6 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
             b_nxt[t] = bp[(t / R) * IW_t + (t % R)];
           }
           // staging work of this step, spread over the slots (CPS items + 1 dy item per step)
-          constexpr int SPREAD = (RS >= 9) ? ((CPS == 4) ? 2 : 1) : 0;  // slot distance between staging items
           if (RS >= 9) {
             if (st < HALF) {
               if (CPS == 4 ? ((t & 1) == 1 && t / 2 < CPS) : (t < CPS)) load_x(st * CPS + (CPS == 4 ? t / 2 : t));
@@ -883,7 +887,6 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
               store_d(dl_n, st - HALF);
             }
           }
-          (void)SPREAD;
           __builtin_amdgcn_sched_barrier(0);
         }
         a_cur = a_nxt;

@@ -231,7 +231,8 @@ int salun_conv2d_backward_weight(const float *x /*dev*/, const float *dy /*dev*/
 size_t salun_bn_workspace_bytes(int C);
 int salun_bn_forward(const float *x /*dev*/, const float *res /*dev or NULL*/, float *y /*dev*/,
                      const float *gamma /*dev*/, const float *beta /*dev*/, float *running_mean /*dev or NULL*/,
-                     float *running_var /*dev or NULL*/, float *save_mean /*dev*/, float *save_invstd /*dev*/,
+                     float *running_var /*dev or NULL*/, long long *num_batches_tracked /*dev or NULL: += 1 if training*/,
+                     float *save_mean /*dev*/, float *save_invstd /*dev*/,
                      int N, int C, int HW, int training, double momentum, double eps, int relu, void *ws /*dev*/,
                      size_t ws_bytes, salun_stream_t stream);
 int salun_bn_backward(const float *dy /*dev*/, const float *y /*dev, needed if relu*/, const float *x /*dev*/,

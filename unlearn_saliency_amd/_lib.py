@@ -57,7 +57,7 @@ SIGNATURES = {
     "salun_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_size_t,
                                                                                           c_void_p]),
     "salun_bn_workspace_bytes": (c_size_t, [c_int]),
-    "salun_bn_forward": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_double, c_double, c_int, c_void_p, c_size_t, c_void_p]),
+    "salun_bn_forward": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_double, c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_bn_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_backward_data_add": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "salun_gn_workspace_bytes": (c_size_t, [c_int, c_int]),

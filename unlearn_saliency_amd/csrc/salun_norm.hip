@@ -86,10 +86,12 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, c
                                                   float *__restrict__ mean, float *__restrict__ invstd,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                   float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                  int N, int C, int HW, int nsplit, float eps, float momentum) {
+                                                  long long *__restrict__ num_batches_tracked, int N, int C, int HW,
+                                                  int nsplit, float eps, float momentum) {
   __shared__ float st[2];
   const int c = blockIdx.x, s = blockIdx.y;
   if (TRAIN) {
+    if (num_batches_tracked && c == 0 && s == 0 && threadIdx.x == 0) *num_batches_tracked += 1;  // nn.BatchNorm2d's counter
     bn_channel_stats(partial, c, nsplit, (double)N * HW, eps, st, s == 0, momentum, mean, invstd, running_mean,
                      running_var);
   } else {
@@ -243,9 +245,10 @@ SALUN_EXPORT size_t salun_bn_workspace_bytes(int C) {
 // training != 0: batch statistics -> mean/invstd (saved for backward) and running-stat update (if pointers given);
 // training == 0: mean/invstd from the running statistics.  Then y = [relu](gamma*(x-mean)*invstd + beta [+ res]).
 SALUN_EXPORT int salun_bn_forward(const float *x, const float *res, float *y, const float *gamma, const float *beta,
-                                  float *running_mean, float *running_var, float *save_mean, float *save_invstd,
-                                  int N, int C, int HW, int training, double momentum, double eps, int relu, void *ws,
-                                  size_t ws_bytes, salun_stream_t stream) {
+                                  float *running_mean, float *running_var, long long *num_batches_tracked,
+                                  float *save_mean, float *save_invstd, int N, int C, int HW, int training,
+                                  double momentum, double eps, int relu, void *ws, size_t ws_bytes,
+                                  salun_stream_t stream) {
   if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || N < 1 || C < 1 || HW < 4 || (HW & 3))
     return SALUN_EINVAL;
   if (!training && (!running_mean || !running_var)) return SALUN_EINVAL;
@@ -260,8 +263,8 @@ SALUN_EXPORT int salun_bn_forward(const float *x, const float *res, float *y, co
   }
 #define SALUN_BN_APPLY(RELU_, RES_, TRAIN_)                                                                       \
   hipLaunchKernelGGL((k_bn_apply<RELU_, RES_, TRAIN_>), dim3(C, ns), dim3(256), 0, st, x, res, y, partial,         \
-                     save_mean, save_invstd, gamma, beta, running_mean, running_var, N, C, HW, ns, (float)eps,    \
-                     (float)momentum)
+                     save_mean, save_invstd, gamma, beta, running_mean, running_var, num_batches_tracked, N, C,  \
+                     HW, ns, (float)eps, (float)momentum)
   const bool r = relu != 0, a = res != nullptr, t = training != 0;
   if (r && a && t) SALUN_BN_APPLY(true, true, true);
   else if (r && a) SALUN_BN_APPLY(true, true, false);

@@ -17,8 +17,8 @@ from . import gradsink, ops
 
 class _FusedBN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
-        out = ops.bn_forward(x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu)
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, nbt=None):
+        out = ops.bn_forward(x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, nbt)
         if out is None:
             raise RuntimeError("fused BN: unsupported shape (H*W must be a multiple of 4)")
         y, mean, invstd = out
@@ -40,7 +40,7 @@ class _FusedBN(torch.autograd.Function):
             gradsink.arrived(weight)
             gradsink.arrived(bias)
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 def _eligible(x: torch.Tensor, bn: nn.BatchNorm2d) -> bool:
@@ -57,10 +57,8 @@ def fused_bn_act(x: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor = N
     x = x.contiguous()
     if residual is not None:
         residual = residual.contiguous()
-    if bn.training:
-        bn.num_batches_tracked.add_(1)
     return _FusedBN.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.training,
-                          bn.momentum, bn.eps, relu)
+                          bn.momentum, bn.eps, relu, bn.num_batches_tracked)  # the kernel bumps the counter
 
 
 class _FusedGN(torch.autograd.Function):

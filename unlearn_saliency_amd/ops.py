@@ -267,7 +267,8 @@ def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: i
 
 
 # ------------------------------------------------------------------- fused BatchNorm
-def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
+               num_batches_tracked=None):
     """-> (y, save_mean, save_invstd) or None when the shape is outside the kernel's domain (HW % 4 != 0)."""
     N, C, H, W = x.shape
     L = _lib.lib()
@@ -278,7 +279,9 @@ def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentu
     rc = L.salun_bn_forward(_dev(x, torch.float32, "x"), _dev(res, torch.float32, "res", True), c_void_p(y.data_ptr()),
                             _dev(gamma, torch.float32, "weight"), _dev(beta, torch.float32, "bias"),
                             _dev(running_mean, torch.float32, "running_mean", True),
-                            _dev(running_var, torch.float32, "running_var", True), c_void_p(mean.data_ptr()),
+                            _dev(running_var, torch.float32, "running_var", True),
+                            _dev(num_batches_tracked, torch.int64, "num_batches_tracked", True),
+                            c_void_p(mean.data_ptr()),
                             c_void_p(invstd.data_ptr()), N, C, H * W, int(bool(training)), c_double(momentum),
                             c_double(eps), int(bool(relu)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream())
     if rc == _lib.SALUN_EINVAL:

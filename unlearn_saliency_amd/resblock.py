@@ -33,20 +33,16 @@ class _BasicBlockFn(torch.autograd.Function):
         P, Q = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
         training = blk.bn1.training
         c1 = ops.conv2d_forward(x, w1, None, s, 1, P, Q)
-        y1, m1, i1 = ops.bn_forward(c1, None, g1, b1, *_bn_args(blk.bn1), True)
+        y1, m1, i1 = ops.bn_forward(c1, None, g1, b1, *_bn_args(blk.bn1), True, blk.bn1.num_batches_tracked)
         c2 = ops.conv2d_forward(y1, w2, None, 1, 1, P, Q)
         cd = md = idd = None
         if wd is not None:
             cd = ops.conv2d_forward(x, wd, None, s, 0, P, Q)
-            skip, md, idd = ops.bn_forward(cd, None, gd, bd, *_bn_args(blk.downsample[1]), False)
+            skip, md, idd = ops.bn_forward(cd, None, gd, bd, *_bn_args(blk.downsample[1]), False,
+                                           blk.downsample[1].num_batches_tracked)
         else:
             skip = x
-        out, m2, i2 = ops.bn_forward(c2, skip, g2, b2, *_bn_args(blk.bn2), True)
-        if training:
-            blk.bn1.num_batches_tracked.add_(1)
-            blk.bn2.num_batches_tracked.add_(1)
-            if wd is not None:
-                blk.downsample[1].num_batches_tracked.add_(1)
+        out, m2, i2 = ops.bn_forward(c2, skip, g2, b2, *_bn_args(blk.bn2), True, blk.bn2.num_batches_tracked)
         ctx.save_for_backward(x, c1, y1, c2, out, cd, w1, g1, b1, w2, g2, b2, wd, gd, bd, m1, i1, m2, i2, md, idd)
         ctx.cfg = (s, training)
         return out

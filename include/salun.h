@@ -81,7 +81,11 @@ int salun_saliency_accumulate(float *acc /*dev*/, const float *g /*dev*/,
  * `acc` is NOT modified (the abs is fused).  ks[] and masks_out[] are HOST
  * arrays (read before return); masks_out[j] are device pointers to n bytes.
  * 1 <= nk <= SALUN_MAX_THRESHOLDS.
- * Algorithmic traffic: 4 B read + nk B written per element. */
+ * Algorithmic traffic: 4 B read + nk B written per element.
+ * Implementation: radix select (3 histogram passes + 1 write pass); for nk == 1 and
+ * n >= 2^25 a sampled single-pass route is tried first (sample -> bracket -> one pass ->
+ * exact select among ~1 % candidates) with a device-side fallback to the full scan —
+ * the resulting mask is the same function of the input either way. */
 size_t salun_mask_topk_workspace_bytes(int64_t n, int nk);
 int salun_mask_topk(const float *acc /*dev*/, int64_t n, const int64_t *ks /*host*/,
                     int nk, uint8_t *const *masks_out /*host array of dev ptrs*/,

@@ -179,6 +179,70 @@ def test_topk_ddpm_size_property(ops, oracle_mod):
     assert tau == lo_sel
 
 
+# ----------------------------------------------------------- sampled single-pass top-k (one threshold, large N)
+def _sampled_cases(oracle_mod, n):
+    from fixtures import saliency_vector_wide
+    uniq = saliency_vector_wide(n, 77)                       # almost surely unique threshold: the sampled path publishes
+    ties = oracle_mod.fill_normal(n, 5, 0, 1e-3)             # few distinct values: threshold splits a run -> full scan
+    nans = uniq.copy(); nans[::1000] = np.nan; nans[7] = np.inf
+    periodic = np.tile(np.array([1e-3, 5.0, 2e-3, 7.0], np.float32), n // 4 + 1)[:n]  # four values in a fixed cycle
+    ramp = (np.arange(n, dtype=np.float32) / n)              # sorted: index and rank fully correlated
+    return {"unique": uniq, "ties": ties, "nans": nans, "periodic": periodic, "ramp": ramp}
+
+
+@pytest.mark.parametrize("n", [70_001, 1_000_003, N18])
+def test_topk_sampled_path_bit_exact(ops, oracle_mod, monkeypatch, n):
+    """The sampled path (forced on below its switch-over size through the test hook) returns exactly the full-scan
+    answer: published when the bracket holds and the threshold is untied (N18: 1 % candidates fit the buffer),
+    silently deferring to the full scan otherwise (small N: the bracket is wider than the candidate buffer;
+    tied thresholds; periodic data)."""
+    monkeypatch.setenv("SALUN_TOPK_SAMPLED_MIN", "1")
+    cases = _sampled_cases(oracle_mod, n)
+    plan = [(name, k) for name in cases for k in (1, 7, n // 10, n // 2, n - n // 7, n - 1)]
+    if n == N18:  # the CPU oracle sorts 11 M values per call: keep the list short
+        plan = [("unique", 1), ("unique", n // 2), ("unique", n - 1), ("periodic", n // 2), ("nans", n // 3)]
+    for name, k in plan:
+        acc = cases[name]
+        d = dev(acc)
+        for k in (k,):
+            got = ops.mask_topk(d, [k])[0]
+            want = oracle_mod.mask_topk(acc, [k])[0]
+            assert np.array_equal(got.cpu().numpy(), want), (name, k)
+            tau = ops.mask_topk_thresholds(d.device, 1)[0].item()
+            sel = np.abs(acc[want.astype(bool)])
+            kth = np.nan if np.isnan(sel).any() else sel.min()
+            assert (np.isnan(tau) and np.isnan(kth)) or tau == kth, (name, k, tau, kth)
+
+
+def test_topk_sampled_path_at_scale(ops, oracle_mod):
+    """2^26 + 3 elements (default switch-over size): popcount == k, selected >= unselected, threshold exported;
+    and the same mask as the full-scan path (hook raised above N)."""
+    import os
+    n = (1 << 26) + 3
+    d = ops.fill_normal(n, 123, 0.0, 1e-3) * (1.0 + ops.fill_uniform(n, 124, 0.0, 0.5))
+    k = int(n * 0.5)
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    m = ops.mask_topk(d, [k])[0]
+    t0.record(); m = ops.mask_topk(d, [k])[0]; t1.record()
+    torch.cuda.synchronize()
+    tau = ops.mask_topk_thresholds(d.device, 1)[0].item()
+    assert ops.mask_popcount(m) == k
+    a = d.abs()
+    assert a[m.bool()].min().item() >= a[~m.bool()].max().item()
+    assert tau == a[m.bool()].min().item()
+    os.environ["SALUN_TOPK_SAMPLED_MIN"] = str(1 << 40)
+    try:
+        t2 = torch.cuda.Event(enable_timing=True); t3 = torch.cuda.Event(enable_timing=True)
+        full = ops.mask_topk(d, [k])[0]
+        t2.record(); full = ops.mask_topk(d, [k])[0]; t3.record()
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["SALUN_TOPK_SAMPLED_MIN"]
+    assert torch.equal(m, full)
+    print(f"top-k at N = 2^26+3: sampled {t0.elapsed_time(t1):.3f} ms, full scan {t2.elapsed_time(t3):.3f} ms")
+
+
 def test_mask_format_roundtrip(ops, oracle_mod):
     n = 100_003
     m = (oracle_mod.fill_u8(n, 5) & 1).astype(np.uint8)

@@ -15,7 +15,15 @@
 // LDS: per-workgroup histograms (u32, LDS atomics) flushed once with 64-bit global
 // atomics; pass 1/2 histograms are kept per *group* of thresholds that share the
 // already-fixed prefix, so 10 thresholds cost one read of the vector per pass.
+//
+// One threshold over a large vector (N >= 2^25: the DDPM and SD masks) takes the sampled
+// single-pass route first — rank a 2^20-element sample, bracket the threshold, ONE pass
+// over the vector (final mask outside the bracket, ~1 % candidates compacted), exact
+// select among the candidates, fix-up — and falls back to the full scan on the device
+// when the bracket misses; same masks bit for bit (see k_sample ... k_sampled_finish).
 #include "salun_common.h"
+#include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -49,6 +57,9 @@ struct TopkState {
   uint32_t ngroups0, ngroups1;
   uint32_t any_ordered;
   uint32_t nk;
+  uint32_t skip;           // set by the sampled path on success: the full-scan passes below return immediately
+  uint32_t use_kdev;       // take k from kdev[] (computed on the device) instead of the launch argument
+  long long kdev[MAXK];
   uint8_t lut0[D0_BINS];  // d0 -> pass-1 slot + 1 (0 = not a boundary bin)
 };
 
@@ -83,6 +94,7 @@ __device__ __forceinline__ void load_keys(const float *__restrict__ acc, int64_t
 template <bool ALIGNED>
 __global__ __launch_bounds__(SALUN_BLOCK) void k_hist0(const float *__restrict__ acc, int64_t n, TopkState *st) {
   __shared__ uint32_t h[D0_BINS];
+  if (st->skip) return;
   for (int i = threadIdx.x; i < D0_BINS; i += SALUN_BLOCK) h[i] = 0;
   __syncthreads();
   const int64_t nvec = (n + 3) >> 2;
@@ -112,6 +124,7 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_hist0(const float *__restrict__
 template <int LEVEL, bool ALIGNED>
 __global__ __launch_bounds__(SALUN_BLOCK) void k_hist12(const float *__restrict__ acc, int64_t n, TopkState *st) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  if (st->skip) return;
   const uint32_t ngroups = (LEVEL == 1) ? st->ngroups0 : st->ngroups1;
   if (ngroups == 0) return;  // every threshold is trivial (k <= 0 or k >= n)
   uint8_t *lut = reinterpret_cast<uint8_t *>(lds);  // 2048 bytes
@@ -174,6 +187,7 @@ __global__ __launch_bounds__(1024) void k_select(TopkState *st, int64_t n, KList
   const int nk = kl.nk;
   constexpr int NBINS = (LEVEL == 0) ? D0_BINS : 1024;
   constexpr int PER_LANE = NBINS / 64;
+  if (st->skip) return;
   __shared__ uint32_t s_bin[MAXK];
   __shared__ u64 s_rem[MAXK];
   __shared__ u64 s_cnt[MAXK];
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(1024) void k_select(TopkState *st, int64_t n, KList
     uint32_t mode = MODE_NONE;
     long long k = 0;
     if ((int)threadIdx.x < nk) {
-      k = kl.k[threadIdx.x];
+      k = st->use_kdev ? st->kdev[threadIdx.x] : kl.k[threadIdx.x];
       if (k <= 0) { k = 0; mode = MODE_NONE; }
       else if (k > n) { k = n; mode = MODE_ALL; }  // k == n runs the select: its threshold (the minimum) is real
       else mode = MODE_GE;  // provisional: refined after the last level
@@ -276,7 +290,7 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(SALUN_BLOCK) void k_tie_count(const float *__restrict__ acc, int64_t n,
                                                            const TopkState *st, u64 *tie /*[nk][nchunk]*/,
                                                            int64_t nchunk) {
-  if (!st->any_ordered) return;
+  if (st->skip || !st->any_ordered) return;
   __shared__ uint32_t lds4[4];
   const int nk = (int)st->nk;
   const int64_t nvec = (n + 3) >> 2;
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_tie_count(const float *__restri
 
 // One workgroup per threshold: in-place exclusive scan over chunks.
 __global__ __launch_bounds__(SALUN_BLOCK) void k_tie_scan(const TopkState *st, u64 *tie, int64_t nchunk) {
-  if (!st->any_ordered) return;
+  if (st->skip || !st->any_ordered) return;
   const int j = blockIdx.x;
   if (st->mode[j] != MODE_ORDERED) return;
   __shared__ u64 s_wave[4];
@@ -358,6 +372,7 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_write_masks(const float *__rest
   __shared__ uint32_t s_tau[MAXK];
   __shared__ u64 s_budget[MAXK];
   __shared__ uint32_t lds4[4];
+  if (st->skip) return;
   const int nk = (int)st->nk;
   if ((int)threadIdx.x < nk) {
     const uint32_t mode = st->mode[threadIdx.x];
@@ -505,7 +520,250 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_sum_partials_i64(const u64 *__r
   if (threadIdx.x == 0) *out = (long long)(lds[0] + lds[1] + lds[2] + lds[3]);
 }
 
+// =====================================================================================================
+// Sampled single-pass path (one threshold, N >= SAMPLED_MIN_N): the three histogram passes above read the vector
+// three times before the write pass reads it a fourth time.  For SD-sized vectors (3.4 GB) that is the whole cost.
+// Here a strided sample of S = 2^20 values is ranked first (same radix select, 4 MB); its order statistics
+// 8 sigma either side of the target rank bracket the true threshold:  lo <= tau <= hi  except with
+// probability ~1e-15 for exchangeable data.  ONE pass over the vector then
+//     writes mask = [key > hi]                      (final for everything outside the bracket)
+//     counts c_gt = #{key > hi}
+//     compacts the ~0.8 % of elements with lo <= key <= hi (|value| and flat index)
+// and the exact threshold is the (k - c_gt)-th largest of the compacted values (radix select over ~N/126 elements),
+// after which those candidates' mask bytes are fixed up.  The result is the same function of the input as the
+// full-scan path (bit-exact masks).  Whenever the bracket misses (adversarial periodic data), the candidate buffer
+// overflows or the threshold splits a run of equal keys, nothing is published and the full-scan passes run as
+// before — they start with `if (st->skip) return`.
+constexpr int64_t SAMPLED_MIN_N = int64_t(1) << 25;  // measured cross-over with the full scan: ~30 M elements (tools/topk_scale.py)
+constexpr int SAMPLE_LOG2 = 20;
+
+constexpr int TIE_CAP = 4096;   // tied candidates that can be ordered by index in one workgroup
+
+struct SampCounters {
+  u64 c_gt;          // elements strictly above the bracket
+  u64 m;             // candidates kept
+  uint32_t overflow; // some workgroup ran out of its slab of the candidate buffer
+  uint32_t ok;
+  uint32_t tie_n;    // candidates equal to the threshold (ordered-tie case only)
+};
+struct SampExtra {
+  TopkState samp;    // select on the sample: threshold 0 = upper bracket, 1 = lower bracket
+  TopkState cand;    // select on the candidates
+  SampCounters cnt;
+  uint32_t tie_idx[TIE_CAP];
+};
+
+__global__ __launch_bounds__(SALUN_BLOCK) void k_sample(const float *__restrict__ acc, int64_t stride, int64_t S,
+                                                        float *__restrict__ out) {
+  // one element per stride window at a hashed offset: a fixed offset would lock onto periodic structure of the
+  // flat vector (e.g. always the centre tap of 3x3 kernels when the stride is a multiple of 9)
+  const int64_t s = (int64_t)blockIdx.x * SALUN_BLOCK + threadIdx.x;
+  if (s < S) out[s] = acc[s * stride + (int64_t)(salun_splitmix64((uint64_t)s) % (uint64_t)stride)];
+}
+
+// The one full pass.  Every workgroup appends its candidates to its own slab of the candidate buffer (LDS counter:
+// no contended global atomic); unused slab entries keep their NaN fill, which ranks after every number.
+template <bool ALIGNED, bool MALIGNED>
+__global__ __launch_bounds__(SALUN_BLOCK) void k_sampled_main(const float *__restrict__ acc, int64_t n,
+                                                              const TopkState *samp, int no_hi, int no_lo,
+                                                              uint8_t *__restrict__ mask, float *__restrict__ candv,
+                                                              uint32_t *__restrict__ candi, u64 slab_cap,
+                                                              SampCounters *cnt) {
+  __shared__ uint32_t s_count;
+  __shared__ u64 s_w[4];
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  const uint32_t hi_key = no_hi ? 0xFFFFFFFFu : samp->tau[0];
+  const uint32_t lo_key = no_lo ? 0u : samp->tau[1];
+  const int lane = threadIdx.x & 63;
+  const int64_t nvec = (n + 3) >> 2;
+  const int64_t nchunk = (nvec + CHUNK_VEC - 1) / CHUNK_VEC;
+  float *myv = candv + (u64)blockIdx.x * slab_cap;
+  uint32_t *myi = candi + (u64)blockIdx.x * slab_cap;
+  uint32_t my_gt = 0;
+  u64 blk_gt = 0;
+  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    uint32_t k[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
+      if (v < nvec) load_keys<ALIGNED>(acc, v, n, k[u]);
+      else k[u][0] = k[u][1] = k[u][2] = k[u][3] = KEY_SKIP;
+    }
+    uint32_t ncand = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      uint32_t bits = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t key = k[u][e];
+        const bool real = key != KEY_SKIP;
+        const bool gt = real && key > hi_key;
+        bits |= (uint32_t)gt << (8 * e);
+        my_gt += gt;
+        ncand += (real && !gt && key >= lo_key);
+      }
+      const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
+      if (v < nvec) {
+        const int64_t i = v << 2;
+        if (MALIGNED && i + 3 < n) {
+          reinterpret_cast<uint32_t *>(mask)[v] = bits;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (i + e < n) mask[i + e] = (uint8_t)((bits >> (8 * e)) & 1u);
+        }
+      }
+    }
+    // wave-aggregated append into the workgroup's slab
+    uint32_t inc = ncand;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    const uint32_t wave_total = __shfl(inc, 63, 64);
+    if (wave_total) {
+      uint32_t base = 0;
+      if (lane == 63) base = atomicAdd(&s_count, wave_total);
+      base = __shfl(base, 63, 64);
+      u64 pos = (u64)base + (inc - ncand);
+      if (ncand) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t key = k[u][e];
+            if (key != KEY_SKIP && key <= hi_key && key >= lo_key) {
+              if (pos < slab_cap) {
+                myv[pos] = key ? __uint_as_float(key - 1u) : __uint_as_float(0x7FC00000u);  // |x| (NaN for key 0)
+                myi[pos] = (uint32_t)(((c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x) << 2) + e);
+              }
+              ++pos;
+            }
+          }
+      }
+    }
+    if (my_gt > 0x7FFFFFFFu) { blk_gt += my_gt; my_gt = 0; }
+  }
+  blk_gt += my_gt;
+  u64 v = salun_wave_sum_u64(blk_gt);
+  if (lane == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u64 tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (tot) atomicAdd(&cnt->c_gt, tot);
+    const u64 mine = s_count;
+    if (mine > slab_cap) cnt->overflow = 1;
+    if (mine) atomicAdd(&cnt->m, mine < slab_cap ? mine : slab_cap);
+  }
+}
+
+__global__ void k_sampled_prep(SampExtra *ex, long long k) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const u64 m = ex->cnt.m;
+  const long long r = k - (long long)ex->cnt.c_gt;
+  const bool ok = !ex->cnt.overflow && r >= 1 && (u64)r <= m;
+  ex->cnt.ok = ok ? 1u : 0u;
+  ex->cand.kdev[0] = ok ? r : 1;
+  ex->cand.use_kdev = 1;
+}
+
+// candidates above the exact threshold -> 1; equal to it -> 1 (all ties inside the budget) or collected for ordering
+__global__ __launch_bounds__(SALUN_BLOCK) void k_sampled_fixup(const float *__restrict__ candv,
+                                                               const uint32_t *__restrict__ candi, SampExtra *ex,
+                                                               u64 cap, uint8_t *__restrict__ mask) {
+  if (!ex->cnt.ok) return;
+  const uint32_t tau = ex->cand.tau[0];
+  const uint32_t mode = ex->cand.mode[0];
+  if (tau == 0 || mode < MODE_GE) return;  // NaN threshold: slab padding is indistinguishable -> full scan
+  for (u64 i = (u64)blockIdx.x * SALUN_BLOCK + threadIdx.x; i < cap; i += (u64)gridDim.x * SALUN_BLOCK) {
+    const uint32_t key = key_of(candv[i]);
+    if (key > tau || (key == tau && mode == MODE_GE)) {
+      mask[candi[i]] = 1;
+    } else if (key == tau) {
+      const uint32_t pos = atomicAdd(&ex->cnt.tie_n, 1u);
+      if (pos < (uint32_t)TIE_CAP) ex->tie_idx[pos] = candi[i];
+    }
+  }
+}
+
+// one workgroup: order the tied candidates by flat index, admit the first `rem`, publish, switch the full scan off
+__global__ __launch_bounds__(1024) void k_sampled_finish(SampExtra *ex, TopkState *main_state, long long k,
+                                                         uint8_t *__restrict__ mask) {
+  __shared__ uint32_t s_idx[TIE_CAP];
+  if (!ex->cnt.ok) return;
+  const uint32_t tau = ex->cand.tau[0];
+  const uint32_t mode = ex->cand.mode[0];
+  if (tau == 0 || mode < MODE_GE) return;
+  if (mode == MODE_ORDERED) {
+    const uint32_t T = ex->cnt.tie_n;
+    if (T > (uint32_t)TIE_CAP || (u64)T != ex->cand.ceq[0]) return;  // too many ties for this path -> full scan
+    const u64 budget = ex->cand.rem[0];
+    for (uint32_t t = threadIdx.x; t < T; t += 1024) s_idx[t] = ex->tie_idx[t];
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += 1024) {
+      const uint32_t mine = s_idx[t];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < T; ++j) rank += (s_idx[j] < mine);
+      if ((u64)rank < budget) mask[mine] = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // publish for salun_mask_topk_thresholds; the full-scan kernels see skip and return
+    main_state->nk = 1;
+    main_state->k[0] = k;
+    main_state->mode[0] = MODE_GE;
+    main_state->tau[0] = tau;
+    main_state->skip = 1;
+  }
+}
+
+inline int64_t sampled_min_n() {
+  const char *e = getenv("SALUN_TOPK_SAMPLED_MIN");  // test hook: exercise the sampled path at small sizes
+  if (e && *e) return (int64_t)atoll(e);
+  return SAMPLED_MIN_N;
+}
+inline bool sampled_applies(int64_t n, int nk) {
+  return nk == 1 && n >= sampled_min_n() && n >= 65536 && n < (int64_t(1) << 32);
+}
+inline int64_t sample_size(int64_t n) {
+  int64_t S = int64_t(1) << SAMPLE_LOG2;
+  while (S > 4096 && S * 16 > n) S >>= 1;
+  return S;
+}
+inline u64 cand_capacity(int64_t n) { return (u64)(((n / 64 + 4095) / 4096) * 4096 + 4096); }
+inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
 inline size_t state_bytes() { return (sizeof(TopkState) + 255) & ~size_t(255); }
+
+// the three histogram + selection rounds over `data` (state zeroed by the caller): fills state->tau / mode / rem
+inline int run_select(const float *data, int64_t n, const KList &kl, TopkState *state, hipStream_t st) {
+  const bool aligned = salun_aligned16(data);
+  const int grid = salun_grid_for(n, CHUNK);
+  // Histogram kernels end with one global atomic per non-empty bin per workgroup, all workgroups hitting the
+  // same few hundred addresses: keep that chain short (2 workgroups per CU) — the read side still has
+  // 8 waves x 4 KiB in flight per CU.
+  const int hgrid = grid < HIST_MAX_GRID ? grid : HIST_MAX_GRID;
+  // dynamic LDS of the pass-1/2 histogram kernels: 2 KiB lut + one 4 KiB histogram per threshold
+  const size_t lds_bytes = D0_BINS + sizeof(uint32_t) * (size_t)kl.nk * 1024;
+  if (aligned) hipLaunchKernelGGL(k_hist0<true>, dim3(hgrid), dim3(SALUN_BLOCK), 0, st, data, n, state);
+  else hipLaunchKernelGGL(k_hist0<false>, dim3(hgrid), dim3(SALUN_BLOCK), 0, st, data, n, state);
+  SALUN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_select<0>, dim3(1), dim3(1024), 0, st, state, n, kl);
+  SALUN_LAUNCH_CHECK();
+  if (aligned) hipLaunchKernelGGL((k_hist12<1, true>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, data, n, state);
+  else hipLaunchKernelGGL((k_hist12<1, false>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, data, n, state);
+  SALUN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_select<1>, dim3(1), dim3(1024), 0, st, state, n, kl);
+  SALUN_LAUNCH_CHECK();
+  if (aligned) hipLaunchKernelGGL((k_hist12<2, true>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, data, n, state);
+  else hipLaunchKernelGGL((k_hist12<2, false>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, data, n, state);
+  SALUN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_select<2>, dim3(1), dim3(1024), 0, st, state, n, kl);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
 inline int64_t chunks_of(int64_t n) { return (n + CHUNK - 1) / CHUNK; }
 
 }  // namespace
@@ -513,7 +771,11 @@ inline int64_t chunks_of(int64_t n) { return (n + CHUNK - 1) / CHUNK; }
 // ================================================================== C-ABI =======
 SALUN_EXPORT size_t salun_mask_topk_workspace_bytes(int64_t n, int nk) {
   if (n < 0 || nk < 1 || nk > MAXK) return 0;
-  return state_bytes() + sizeof(u64) * (size_t)nk * (size_t)(chunks_of(n) + 1);
+  size_t b = align256(state_bytes() + sizeof(u64) * (size_t)nk * (size_t)(chunks_of(n) + 1));
+  if (sampled_applies(n, nk))
+    b += align256(sizeof(SampExtra)) + align256(sizeof(float) * (size_t)sample_size(n)) +
+         2 * align256(sizeof(float) * (size_t)cand_capacity(n));
+  return b;
 }
 
 SALUN_EXPORT int salun_mask_topk(const float *acc, int64_t n, const int64_t *ks, int nk,
@@ -540,28 +802,62 @@ SALUN_EXPORT int salun_mask_topk(const float *acc, int64_t n, const int64_t *ks,
   const bool aligned = salun_aligned16(acc);
   if (hipMemsetAsync(state, 0, sizeof(TopkState), st) != hipSuccess) return SALUN_EIO;
   const int grid = salun_grid_for(n, CHUNK);
-  // Histogram kernels end with one global atomic per non-empty bin per workgroup, all workgroups hitting the
-  // same few hundred addresses: keep that chain short (2 workgroups per CU) — the read side still has
-  // 8 waves x 4 KiB in flight per CU.
-  const int hgrid = grid < HIST_MAX_GRID ? grid : HIST_MAX_GRID;
-  // dynamic LDS of the pass-1/2 histogram kernels: 2 KiB lut + one 4 KiB histogram per threshold
-  const size_t lds_bytes = D0_BINS + sizeof(uint32_t) * (size_t)nk * 1024;
 
-  if (aligned) hipLaunchKernelGGL(k_hist0<true>, dim3(hgrid), dim3(SALUN_BLOCK), 0, st, acc, n, state);
-  else hipLaunchKernelGGL(k_hist0<false>, dim3(hgrid), dim3(SALUN_BLOCK), 0, st, acc, n, state);
-  SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_select<0>, dim3(1), dim3(1024), 0, st, state, n, kl);
-  SALUN_LAUNCH_CHECK();
-  if (aligned) hipLaunchKernelGGL((k_hist12<1, true>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
-  else hipLaunchKernelGGL((k_hist12<1, false>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
-  SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_select<1>, dim3(1), dim3(1024), 0, st, state, n, kl);
-  SALUN_LAUNCH_CHECK();
-  if (aligned) hipLaunchKernelGGL((k_hist12<2, true>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
-  else hipLaunchKernelGGL((k_hist12<2, false>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, state);
-  SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_select<2>, dim3(1), dim3(1024), 0, st, state, n, kl);
-  SALUN_LAUNCH_CHECK();
+  if (sampled_applies(n, nk) && ks[0] > 0 && ks[0] < n) {
+    // ---- sampled single-pass attempt (see the comment above k_sample); publishes and sets state->skip on success
+    char *base = static_cast<char *>(ws) + align256(state_bytes() + sizeof(u64) * (size_t)nk * (size_t)(nchunk + 1));
+    SampExtra *ex = reinterpret_cast<SampExtra *>(base);
+    const int64_t S = sample_size(n);
+    const u64 cap = cand_capacity(n);
+    float *samp = reinterpret_cast<float *>(base + align256(sizeof(SampExtra)));
+    float *candv = reinterpret_cast<float *>(reinterpret_cast<char *>(samp) + align256(sizeof(float) * (size_t)S));
+    uint32_t *candi = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(candv) + align256(sizeof(float) * cap));
+    if (hipMemsetAsync(ex, 0, sizeof(SampExtra), st) != hipSuccess) return SALUN_EIO;
+    if (hipMemsetAsync(candv, 0xFF, sizeof(float) * cap, st) != hipSuccess) return SALUN_EIO;  // NaN: ranks last
+    const double pfrac = (double)ks[0] / (double)n;
+    const double sigma = std::sqrt((double)S * pfrac * (1.0 - pfrac));
+    const int64_t margin = (int64_t)std::ceil(8.0 * sigma) + 64;
+    const int64_t ks_s = (int64_t)std::llround(pfrac * (double)S);
+    const int no_hi = ks_s - margin < 1, no_lo = ks_s + margin > S;
+    KList k2;
+    k2.nk = 2;
+    for (int j = 0; j < MAXK; ++j) k2.k[j] = 0;
+    k2.k[0] = no_hi ? 1 : ks_s - margin;   // descending rank of the upper bracket in the sample
+    k2.k[1] = no_lo ? S : ks_s + margin;   // ... and of the lower bracket
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((S + SALUN_BLOCK - 1) / SALUN_BLOCK)), dim3(SALUN_BLOCK), 0, st, acc,
+                       n / S, S, samp);
+    SALUN_LAUNCH_CHECK();
+    int rc = run_select(samp, S, k2, &ex->samp, st);
+    if (rc != SALUN_OK) return rc;
+    const int mgrid = grid < 2048 ? grid : 2048;
+    const u64 slab_cap = cap / (u64)mgrid;
+#define SALUN_SMAIN(A, M)                                                                                          \
+  hipLaunchKernelGGL((k_sampled_main<A, M>), dim3(mgrid), dim3(SALUN_BLOCK), 0, st, acc, n, &ex->samp, no_hi, no_lo, \
+                     mp.m[0], candv, candi, slab_cap, &ex->cnt)
+    if (aligned && maligned) SALUN_SMAIN(true, true);
+    else if (aligned) SALUN_SMAIN(true, false);
+    else if (maligned) SALUN_SMAIN(false, true);
+    else SALUN_SMAIN(false, false);
+#undef SALUN_SMAIN
+    SALUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sampled_prep, dim3(1), dim3(64), 0, st, ex, (long long)ks[0]);
+    SALUN_LAUNCH_CHECK();
+    KList k1;
+    k1.nk = 1;
+    for (int j = 0; j < MAXK; ++j) k1.k[j] = 0;
+    k1.k[0] = 1;  // replaced on the device by cand.kdev[0]
+    rc = run_select(candv, (int64_t)cap, k1, &ex->cand, st);
+    if (rc != SALUN_OK) return rc;
+    hipLaunchKernelGGL(k_sampled_fixup, dim3(1024), dim3(SALUN_BLOCK), 0, st, candv, candi, ex, cap, mp.m[0]);
+    SALUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sampled_finish, dim3(1), dim3(1024), 0, st, ex, state, (long long)ks[0], mp.m[0]);
+    SALUN_LAUNCH_CHECK();
+  }
+
+  {
+    const int rc = run_select(acc, n, kl, state, st);  // returns at once on the device if the sampled path published
+    if (rc != SALUN_OK) return rc;
+  }
   // rare path, early-exits on the device when no threshold splits a run of ties
   if (aligned) hipLaunchKernelGGL(k_tie_count<true>, dim3(grid), dim3(SALUN_BLOCK), 0, st, acc, n, state, tie, nchunk);
   else hipLaunchKernelGGL(k_tie_count<false>, dim3(grid), dim3(SALUN_BLOCK), 0, st, acc, n, state, tie, nchunk);

@@ -33,16 +33,19 @@ def _dev(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, allow_none: b
     return c_void_p(t.data_ptr())
 
 
-# One scratch buffer per device, grown on demand (stream-ordered reuse on the current stream).
-_ws: dict[int, torch.Tensor] = {}
+# One scratch buffer per (device, stream), grown on demand: reuse is ordered by the stream the kernels run on, so
+# work issued on a side stream (resblock.py overlaps backward-weight with backward-data) never shares scratch with
+# the main stream.
+_ws: dict[tuple, torch.Tensor] = {}
 
 
 def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    w = _ws.get(idx)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws[idx] = w
+        _ws[key] = w
     return w
 
 

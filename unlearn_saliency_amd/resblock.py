@@ -18,7 +18,42 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+import os
+
+from . import dist as sdist
 from . import gradsink, ops
+
+# Backward-weight and backward-data of one convolution depend on the same dY and on nothing of each other.  The
+# backward-weight kernel runs ONE wave per SIMD (register budget) and leaves LDS for a second workgroup, so issuing it
+# on a side stream lets the two kernels share the CUs — the matrix pipes idle less than when either runs alone.
+# SALUN_WGRAD_OVERLAP=0 keeps everything on one stream.
+OVERLAP_WGRAD = os.environ.get("SALUN_WGRAD_OVERLAP", "1") != "0"
+_side_streams: dict = {}
+
+
+def _side_stream(device: torch.device) -> "torch.cuda.Stream":
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+_join_queued: set = set()
+
+
+def _join_at_end_of_backward(device: torch.device) -> None:
+    """Single process: the main stream waits for the side stream ONCE, when the whole backward pass has been issued
+    (autograd's end-of-backward callback) — so after `loss.backward()` returns, gradients are ordered on the current
+    stream as usual, and inside the pass the weight-gradient kernels of one block overlap the next block's work."""
+    if device in _join_queued:
+        return
+    _join_queued.add(device)
+
+    def _join():
+        _join_queued.discard(device)
+        torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
 def _bn_args(bn: nn.BatchNorm2d):
@@ -65,9 +100,21 @@ class _BasicBlockFn(torch.autograd.Function):
                 dg = db = None
             return dx, dres, dg, db
 
+        main = torch.cuda.current_stream(dout.device)
+        side = _side_stream(dout.device) if OVERLAP_WGRAD else None
+
         def wgrad(xin, dy, w, stride, pad):
             dst = gradsink.sink(w)
-            dw = ops.conv2d_backward_weight(xin, dy, w.shape, stride, pad, out=dst, accumulate=True)
+            if side is None:
+                dw = ops.conv2d_backward_weight(xin, dy, w.shape, stride, pad, out=dst, accumulate=True)
+            else:
+                side.wait_stream(main)  # dy (and everything before it) is complete for the side stream
+                with torch.cuda.stream(side):
+                    dw = ops.conv2d_backward_weight(xin, dy, w.shape, stride, pad, out=dst, accumulate=True)
+                for t in (xin, dy):  # freed when this backward returns: keep the memory until the side stream is done
+                    t.record_stream(side)
+                if dst is None and dw is not None:
+                    dw.record_stream(main)
             if dst is not None:
                 gradsink.arrived(w)
                 return None
@@ -86,6 +133,13 @@ class _BasicBlockFn(torch.autograd.Function):
         dc1, _, dg1, db1 = bn_bwd(dy1, y1, c1, g1, b1, m1, i1, True, False)
         dw1 = wgrad(x, dc1, w1, s, 1)
         dx = ops.conv2d_backward_data(dc1, w1, x.shape, s, 1, addend=dxd) if ctx.needs_input_grad[0] else None
+        if side is not None:
+            if sdist.world_size() > 1 or not all(g is None for g in (dw1, dw2, dwd)):
+                # data parallel: gradient-arrival hooks may start an all-reduce right after this node; autograd
+                # route: AccumulateGrad consumes the returned tensors on the main stream -> join now
+                main.wait_stream(side)
+            else:
+                _join_at_end_of_backward(dout.device)
         return dx, None, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd
 
 

@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import gradsink, ops
+from . import dist as sdist
+from . import gradsink, ops, resblock
 
 
 def _eligible(mod: nn.Conv2d) -> bool:
@@ -41,18 +42,33 @@ class _ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         stride, pad = ctx.stride, ctx.pad
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_backward_data(dy, w, x.shape, stride, pad) if ctx.native else None
-            if dx is None:
-                dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
         if ctx.needs_input_grad[1]:
             dst = gradsink.sink(w) if ctx.native else None
-            dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad, out=dst, accumulate=True) if ctx.native else None
+            # the weight gradient goes straight into .grad (gradsink): nothing on the main stream consumes it before
+            # the end of the backward pass, so it can run on the side stream next to backward-data (resblock.py)
+            overlap = (dst is not None and resblock.OVERLAP_WGRAD and sdist.world_size() == 1)
+            if overlap:
+                main, side = torch.cuda.current_stream(dy.device), resblock._side_stream(dy.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad, out=dst, accumulate=True)
+                if dw is None:  # outside the kernel's domain after all: nothing was launched
+                    overlap = False
+                else:
+                    x.record_stream(side)
+                    dy.record_stream(side)
+                    resblock._join_at_end_of_backward(dy.device)
+            if not overlap:
+                dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad, out=dst, accumulate=True) if ctx.native else None
             if dw is None:
                 dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
             elif dst is not None:  # already added into w.grad by the kernel
                 gradsink.arrived(w)
                 dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_backward_data(dy, w, x.shape, stride, pad) if ctx.native else None
+            if dx is None:
+                dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None

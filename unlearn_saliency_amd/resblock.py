@@ -28,6 +28,14 @@ from . import gradsink, ops
 # on a side stream lets the two kernels share the CUs — the matrix pipes idle less than when either runs alone.
 # SALUN_WGRAD_OVERLAP=0 keeps everything on one stream.
 OVERLAP_WGRAD = os.environ.get("SALUN_WGRAD_OVERLAP", "1") != "0"
+
+
+def reset_join_state() -> None:
+    """Forget a pending end-of-backward join (only needed after a backward pass was aborted by an exception) and make
+    the current streams wait for whatever the side streams still have in flight."""
+    _join_queued.clear()
+    for dev, side in _side_streams.items():
+        torch.cuda.current_stream(dev).wait_stream(side)
 _side_streams: dict = {}
 
 
@@ -44,7 +52,9 @@ _join_queued: set = set()
 def _join_at_end_of_backward(device: torch.device) -> None:
     """Single process: the main stream waits for the side stream ONCE, when the whole backward pass has been issued
     (autograd's end-of-backward callback) — so after `loss.backward()` returns, gradients are ordered on the current
-    stream as usual, and inside the pass the weight-gradient kernels of one block overlap the next block's work."""
+    stream as usual, and inside the pass the weight-gradient kernels of one block overlap the next block's work.
+    Caveat: if a backward pass dies with an exception the engine drops its callbacks; call `reset_join_state()` (or
+    set SALUN_WGRAD_OVERLAP=0) before reusing the process after such a failure."""
     if device in _join_queued:
         return
     _join_queued.add(device)

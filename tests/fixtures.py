@@ -155,3 +155,15 @@ def ewc_inputs():
 def fisher_fixture(shapes):
     """Per-parameter Fisher tensors U[0, 50) from the counter-based generator (SURVEY.md §8 F3 fixtures)."""
     return [rng.uniform(int(np.prod(s)), 9000 + 17 * i, 0.0, 50.0).reshape(s) for i, s in enumerate(shapes)]
+
+
+def eval_loaders():
+    """Member / non-member style batches for the SVC_MIA fixture: "test" images are darker and noisier copies of the
+    generator's images, so the model's confidence / entropy features separate the two populations."""
+    def mk(nb, seed, scale):
+        out = []
+        for i, (x, y) in enumerate(tiny_batches(nb, 16, seed)):
+            s = scale if isinstance(scale, float) else scale[i % len(scale)]
+            out.append((torch.from_numpy((x * np.float32(s)).astype(np.float32)), torch.from_numpy(y)))
+        return out
+    return dict(shadow_train=mk(6, 2000, 1.0), shadow_test=mk(4, 2100, 0.15), target_test=mk(3, 2200, (0.15, 1.0, 0.15)))

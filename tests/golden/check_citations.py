@@ -1,12 +1,14 @@
-"""Every `path/file.py:LINE[-LINE]` citation of the reference in the headers, docs and package docstrings points at
-an existing file of the reference checkout with at least that many lines (build container only: the reference does not
-travel to the GPU box, where this test skips)."""
+"""Build-container check (the reference checkout does not travel): every `path/file.py:LINE[-LINE]` citation of the
+reference in the headers, docs and package docstrings points at an existing file with at least that many lines.
+
+    python -m pytest tests/golden/check_citations.py -q        (or: python tests/golden/check_citations.py)
+"""
 import os
 import re
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 PAT = re.compile(r"((?:Classification|DDPM|SD)/[\w\-/\.]+?\.(?:py|yml|yaml|md|txt)):(\d+)(?:-(\d+))?")
 
@@ -41,3 +43,8 @@ def test_reference_citations_resolve():
                 bad.append(f"{os.path.relpath(src, ROOT)}: {rel}:{lo}-{hi} outside 1..{n}")
     assert seen > 50, "citation pattern found too few references"
     assert not bad, "\n".join(bad[:20])
+
+
+if __name__ == "__main__":
+    test_reference_citations_resolve()
+    print("citations ok")

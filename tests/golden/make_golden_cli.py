@@ -1,0 +1,33 @@
+"""Golden table of the reference's command lines: every flag of Classification/arg_parser.py and
+DDPM/train.py with its default, obtained by running the reference's own parsers on an empty / minimal argv.
+
+    python tests/golden/make_golden_cli.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as MG  # noqa: E402
+
+
+def main():
+    out = {}
+    ap = MG._load("ref_arg_parser", MG.REF + "/Classification/arg_parser.py")
+    argv, sys.argv = sys.argv, ["prog"]
+    try:
+        ns = ap.parse_args()
+    finally:
+        sys.argv = argv
+    out["classification_defaults"] = {k: (v if isinstance(v, (int, float, str, bool, type(None))) else repr(v))
+                                      for k, v in sorted(vars(ns).items())}
+    with open(os.path.join(HERE, "cli.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("cli.json written:", len(out["classification_defaults"]), "classification flags")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,35 @@
+"""Command-line surface: every flag of the reference's Classification parser exists here with the
+same default (tests/golden/cli.json, dumped from the reference's own `parse_args`), the build's extra flags are
+optional, and the entry-point parsers construct.  CPU."""
+import json
+import os
+
+import pytest
+
+
+def test_classification_flags_and_defaults_match_reference(golden_dir):
+    from unlearn_saliency_amd.Classification import arg_parser
+    ref = json.load(open(os.path.join(golden_dir, "cli.json")))["classification_defaults"]
+    mine = vars(arg_parser.parse_args([]))
+    assert len(ref) == 43
+    for k, v in ref.items():
+        assert k in mine, f"reference flag --{k} missing"
+        assert mine[k] == v or repr(mine[k]) == v, (k, mine[k], v)
+    extra = set(mine) - set(ref)
+    assert extra == {"synthetic", "device_loader", "mask_ratio", "sync_bn", "library_conv", "thresholds"}
+    a = arg_parser.parse_args(["--unlearn", "RL", "--unlearn_lr", "0.013", "--unlearn_epochs", "10",
+                               "--num_indexes_to_replace", "4500", "--mask_path", "m/with_0.5.pt", "--no-aug"])
+    assert (a.unlearn, a.unlearn_lr, a.num_indexes_to_replace, a.no_aug) == ("RL", 0.013, 4500, True)
+
+
+def test_registry_names_match_reference():
+    from unlearn_saliency_amd.Classification import unlearn
+    names = ["raw", "RL", "GA", "FT", "FT_l1", "fisher", "retrain", "fisher_new", "wfisher", "FT_prune", "FT_prune_bi",
+             "GA_prune", "GA_prune_bi", "GA_l1", "boundary_expanding", "boundary_shrink", "RL_proximal"]
+    for n in names:
+        assert callable(unlearn.get_unlearn_method(n))
+    with pytest.raises(NotImplementedError):
+        unlearn.get_unlearn_method("no_such_method")
+    for n in ("fisher", "retrain", "FT_prune"):  # registered for CLI compatibility, outside the hot path
+        with pytest.raises(NotImplementedError):
+            unlearn.get_unlearn_method(n)(None, None, None, None)

@@ -58,9 +58,6 @@ _REFERENCE_FLAGS = [
     ("--indexes_to_replace", dict(type=list, default=None, help="Specific index data to forget")),
     ("--alpha", dict(type=float, default=0.2, help="unlearn noise")),
     ("--mask_path", dict(type=str, default=None, help="the path of saliency map")),
-    ("--mask_ratio", dict(type=float, default=None,
-                          help="RL_proximal: fraction of weights reset per step at the start of the schedule "
-                               "(read as args.mask_ratio by the reference's RL_pro.py:13, which never defines the flag)")),
 ]
 
 # Extensions of the MI355X build.
@@ -69,7 +66,9 @@ _BUILD_FLAGS = [
                          help="use the counter-based synthetic CIFAR-shaped set (no dataset files needed)")),
     ("--device_loader", dict(action="store_true",
                              help="keep the uint8 dataset resident in HBM and assemble batches on the device")),
-    ("--mask_ratio", dict(type=float, default=0.5, help="ratio read by RL_proximal (missing in the reference parser)")),
+    ("--mask_ratio", dict(type=float, default=0.5,
+                          help="RL_proximal: fraction of weights reset per step at the start of the schedule (read as "
+                               "args.mask_ratio by the reference's RL_pro.py:13, whose parser never defines the flag)")),
     ("--sync_bn", dict(action="store_true", help="SyncBatchNorm under multi-GPU data parallel")),
     ("--library_conv", dict(action="store_true",
                             help="use the library (MIOpen) convolutions instead of the fp32 MFMA kernels")),

@@ -26,3 +26,33 @@ def test_synthetic_pipeline_builds_the_reference_shaped_workload():
     utils.dataset_convert_to_test(forget, args)
     assert forget.transform == "test"
     assert len(_driver._head(retain, len(test_loader.dataset))) == 10000
+
+
+def test_ddpm_config_and_class_forget_loaders():
+    """YAML schema of configs/cifar10_saliency_unlearn.yml and the class-forget split (label 0: 5,000 of 50,000
+    synthetic samples at batch 128 -> 40 forget / 352 remain batches)."""
+    import os
+    from types import SimpleNamespace
+    from unlearn_saliency_amd.DDPM.datasets import get_forget_dataset
+    from unlearn_saliency_amd.DDPM.functions import load_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(root, "unlearn_saliency_amd", "DDPM", "configs", "cifar10_saliency_unlearn.yml"))
+    assert (cfg.model.ch, list(cfg.model.ch_mult), cfg.model.num_res_blocks) == (128, [1, 2, 2, 2], 2)
+    assert (cfg.training.batch_size, cfg.diffusion.num_diffusion_timesteps, cfg.optim.lr) == (128, 1000, 1e-4)
+    remain, forget = get_forget_dataset(SimpleNamespace(label_to_forget=0), cfg, 0, device=torch.device("cpu"),
+                                        synthetic=True)
+    assert (len(remain), len(forget)) == (352, 40)
+    x, c = next(iter(forget))
+    assert x.shape == (128, 3, 32, 32) and bool((c == 0).all())
+    x, c = next(iter(remain))
+    assert bool((c != 0).all())
+
+
+def test_sd_unet_full_configuration_has_the_reference_parameter_table():
+    """SD-v1 U-Net on the meta device: 686 tensors / 859,520,964 parameters (mask keys of SD/train-scripts)."""
+    from unlearn_saliency_amd.SD.unet import V1_UNET_CONFIG, UNetModel
+    with torch.device("meta"):
+        m = UNetModel(**V1_UNET_CONFIG)
+    names = [n for n, _ in m.named_parameters()]
+    assert len(names) == 686 and sum(p.numel() for p in m.parameters()) == 859_520_964
+    assert names[0] == "time_embed.0.weight" and any("attn2.to_k.weight" in n for n in names)

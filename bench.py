@@ -46,11 +46,19 @@ SGD_BYTES_PER_ELEM = 21      # r p,g,buf (12) + r mask (1) + w
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=177,
+                    help="timed steps; the default is ONE epoch of the reference's RL loop (18 forget + 159 retain "
+                         "batches), so both ragged tail batches (148 / 52 samples) are inside the window")
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "ddpm"],
+                    help="resnet18 = BASELINE configs[1] (the headline metric); ddpm = configs[3] at 1 GPU "
+                         "(tools/bench_ddpm.py's line with the same contract fields)")
+    ap.add_argument("--selftest_launcher", action="store_true",
+                    help="host-only check of the --gpus N launcher: N ranks rendezvous (gloo on CPU, RCCL on GPUs), "
+                         "all-reduce a one and rank 0 prints {n_gpus, rccl_ranks}; no workload is run")
     ap.add_argument("--batch_size", type=int, default=256, help="per-GPU batch (reference: 256)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_steps", type=int, default=2, help="reference-sequence steps timed on the host CPU")
+    ap.add_argument("--cpu_steps", type=int, default=5, help="reference-sequence steps timed on the host CPU")
     ap.add_argument("--no_mask_gen", action="store_true", help="skip timing Phase A (a random mask is used)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="1 = keep cudnn.deterministic=True as the reference's setup_seed sets it (restricts MIOpen's "
@@ -65,18 +73,21 @@ def parse():
 
 
 class StepStream:
-    """Endless stream of (image, target, is_forget) batches in the reference's epoch pattern:
+    """Endless stream of (image, target, loss weight of this rank's shard) batches in the reference's epoch pattern:
     all forget batches (random labels) then all retain batches (true labels), reshuffled every epoch."""
 
     def __init__(self, forget_loader, retain_loader, num_classes=10):
         self.fl, self.rl, self.nc = forget_loader, retain_loader, num_classes
 
     def __iter__(self):
+        from unlearn_saliency_amd import dist as sdist
         while True:
             for x, y in self.fl:
-                yield x, torch.randint(0, self.nc, y.shape).to(y.device, non_blocking=True), True
+                lo, hi, b = self.fl.last_shard  # labels drawn for the global batch, sliced to this rank's shard
+                lab = torch.randint(0, self.nc, (b,))[lo:hi]
+                yield x, lab.to(y.device, non_blocking=True), sdist.shard_loss_scale(self.fl)
             for x, y in self.rl:
-                yield x, y, False
+                yield x, y, sdist.shard_loss_scale(self.rl)
 
 
 def build_workload(device, rank, world, per_gpu_bs):
@@ -138,21 +149,77 @@ def cpu_baseline(per_gpu_bs, steps):
     for _ in range(steps):
         torch_ref.rl_step_cpu(model, crit, opt, x, y, mask, theta0, timers)
     dt = time.perf_counter() - t0
+    # the reference's Phase-A ranking (generate_mask.py:46-80: abs, cat, two argsorts of N,
+    # per-tensor compare) for ONE ratio on a ResNet-18-sized gradient dict; the reference repeats it for 10 ratios
+    g = torch.Generator().manual_seed(3)
+    grads = {n: torch.randn(p.shape, generator=g) * 1e-3 for n, p in model.named_parameters()}
+    t1 = time.perf_counter()
+    torch_ref.masks_from_gradients_cpu(grads, [0.5])
+    mask_one = time.perf_counter() - t1
     return {"value": steps / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "mask_topk_sec_one_ratio": mask_one, "mask_topk_sec_10_ratios_extrapolated": 10 * mask_one,
+            "mask_topk_sample": "abs + cat + 2 x argsort(11,173,962) + 62 per-tensor compares for ratio 0.5 "
+                                "(Classification/generate_mask.py:46-80); x10 for the reference's ten ratios",
             "sample": f"{steps} RL steps at batch {per_gpu_bs} (ResNet-18 fp32, reference op sequence: fwd+bwd, "
                       f"62x mask-mul, torch.optim.SGD, 62x restore) after 1 warm-up step",
             "ms_per_step": 1e3 * dt / steps, "host_cpu_count": os.cpu_count(),
             "breakdown_ms": {k: 1e3 * v / steps for k, v in timers.items()}}
 
 
+def selftest_launcher(a):
+    """`--gpus N --selftest_launcher`: prove that N ranks were created and can reduce (gloo on a CPU box)."""
+    from unlearn_saliency_amd import dist as sdist
+    rank, _, world = sdist.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher created WORLD_SIZE={world}")
+    counted = sdist.counted_ranks()
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "rccl_ranks": counted,
+                          "backend": torch.distributed.get_backend() if sdist.is_dist() else None}), flush=True)
+    sdist.barrier()
+    if sdist.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+def ensure_built():
+    """A fresh clone has no libsalun.so: build it (hipcc cross-compiles) instead of dying with ImportError."""
+    from unlearn_saliency_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        with __import__("contextlib").redirect_stdout(sys.stderr):
+            __graft_entry__.build()
+    return _lib.lib()  # raises loudly if the HIP extension still cannot be loaded
+
+
 def main():
     a = parse()
     from unlearn_saliency_amd import dist as sdist
-    from unlearn_saliency_amd import _lib
-    rank, local_rank, world = sdist.init_from_env()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without torchrun: become the launcher of N ranks (one per GPU, RCCL)
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            ensure_built() if not a.selftest_launcher else None
+        raise SystemExit(sdist.launch_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus,
+                                            require_devices=not a.selftest_launcher))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} disagrees with the launcher's WORLD_SIZE={os.environ['WORLD_SIZE']}")
+    if a.selftest_launcher:
+        return selftest_launcher(a)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback for the measured path)")
+    if torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", "1")):
+        raise SystemExit(f"bench.py --gpus {a.gpus} needs {a.gpus} devices, found {torch.cuda.device_count()}")
+    if int(os.environ.get("RANK", "0")) == 0:
+        ensure_built()
+    if a.workload == "ddpm":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_ddpm
+        return bench_ddpm.main(["--steps", str(a.steps), "--warmup", str(a.warmup)]
+                               + (["--no_cpu_baseline"] if a.no_cpu_baseline else []))
+    rank, local_rank, world = sdist.init_from_env()
+    from unlearn_saliency_amd import _lib
     _lib.lib()  # fail loudly if the HIP extension is missing
+    rccl_ranks = sdist.counted_ranks()  # an actual all-reduce over the ranks RCCL sees
+    assert rccl_ranks == world == a.gpus, (rccl_ranks, world, a.gpus)
     device = torch.device("cuda", torch.cuda.current_device())
     torch.backends.cudnn.benchmark = True
 
@@ -193,10 +260,12 @@ def main():
     stream = iter(StepStream(forget_loader, retain_loader))
 
     def one_step(ev=None):
-        x, y, _ = next(stream)
+        x, y, w = next(stream)
         if a.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
         loss = criterion(model(x), y)
+        if w != 1.0:  # data parallel, ragged tail batch: count-weighted shard mean
+            loss = loss * w
         opt.zero_grad()
         loss.backward()
         if ev is not None:
@@ -244,18 +313,27 @@ def main():
     fb_mean_s = 1e-3 * sum(fb_ms) / max(len(fb_ms), 1)
     pmc_traffic, pmc_src = None, None
     try:  # HBM bytes per launch from the committed PMC passes (tools/pmc.sh; never collected inside this run)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc_traffic = json.load(f)["kernels"]["k_masked_sgd_vec@n18"]["traffic_bytes"]
-            pmc_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        for rnd in ("r02", "r01"):
+            pth = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+            if os.path.exists(pth):
+                with open(pth) as f:
+                    pmc_traffic = json.load(f)["kernels"]["k_masked_sgd_vec@n18"]["traffic_bytes"]
+                pmc_src = (f"profiles/{rnd}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                           f"passes over tools/kbench.py, tools/pmc.sh; PMC cannot be collected inside this run)")
+                break
     except Exception:
         pass
 
+    from unlearn_saliency_amd import conv as sconv
+    library_conv_calls = dict(sconv.LIBRARY_CONV_CALLS, total=sconv.library_conv_calls())
     if rank == 0:
         steps_per_s = a.steps * world / dt
         alg_bytes = SGD_BYTES_PER_ELEM * N18
         out = {
             "metric": "unlearn_steps_per_sec (ResNet-18/CIFAR-10 10%-forget, RL + SalUn mask, batch 256/GPU)",
-            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "backend": (torch.distributed.get_backend() if sdist.is_dist() else "single-process"),
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ResNet-18 (11,173,962 params) / CIFAR-10-shaped synthetic set, 10% random-data "
@@ -264,7 +342,7 @@ def main():
                        "per_gpu_batch": a.batch_size, "global_batch": a.batch_size * world,
                        "parallelism": f"dp{world}", "params": N18, "cudnn_deterministic": bool(a.deterministic),
                        "channels_last": bool(a.channels_last), "salun_mfma_convs": n_salun_convs,
-                       "fused_bn_layers": n_fused_bn},
+                       "fused_bn_layers": n_fused_bn, "library_conv_calls": library_conv_calls},
             "samples_per_sec": steps_per_s * a.batch_size,
             "mask_gen_sec": None if mask_gen is None else mask_gen["total_sec"],
             "mask_gen": mask_gen,

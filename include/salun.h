@@ -82,14 +82,29 @@ int salun_saliency_accumulate(float *acc /*dev*/, const float *g /*dev*/,
  * arrays (read before return); masks_out[j] are device pointers to n bytes.
  * 1 <= nk <= SALUN_MAX_THRESHOLDS.
  * Algorithmic traffic: 4 B read + nk B written per element.
- * Implementation: radix select (3 histogram passes + 1 write pass); for nk == 1 and
- * n >= 2^25 a sampled single-pass route is tried first (sample -> bracket -> one pass ->
- * exact select among ~1 % candidates) with a device-side fallback to the full scan —
- * the resulting mask is the same function of the input either way. */
+ * Implementation (csrc/salun_topk.hip): for n >= 8192 and 16-B aligned input the vector is read ONCE — a hashed
+ * sample brackets every threshold, one streaming pass writes the masks outside the brackets and compacts the ~5 % of
+ * elements inside them, and the exact threshold is resolved among those candidates; a persistent full-scan radix
+ * select (3 histogram passes + 1 write pass, grid barriers) handles small / unaligned inputs and is the device-side
+ * fallback when a bracket misses or a candidate buffer overflows (heavy ties) — the resulting mask is the same
+ * function of the input either way.
+ * salun_mask_topk_ex takes flags:
+ *   SALUN_TOPK_FORCE_FULL_SCAN  skip the single-read route (tests / A-B timing)
+ *   SALUN_TOPK_VALUES_ONLY      no masks are written (masks_out may be NULL); only the thresholds are published
+ * salun_mask_topk == salun_mask_topk_ex with flags 0. */
+#define SALUN_TOPK_FORCE_FULL_SCAN 1u
+#define SALUN_TOPK_VALUES_ONLY 2u
 size_t salun_mask_topk_workspace_bytes(int64_t n, int nk);
 int salun_mask_topk(const float *acc /*dev*/, int64_t n, const int64_t *ks /*host*/,
                     int nk, uint8_t *const *masks_out /*host array of dev ptrs*/,
                     void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+int salun_mask_topk_ex(const float *acc /*dev*/, int64_t n, const int64_t *ks /*host*/,
+                       int nk, uint8_t *const *masks_out /*host array of dev ptrs, or NULL*/,
+                       void *ws /*dev*/, size_t ws_bytes, unsigned flags, salun_stream_t stream);
+/* Diagnostic (synchronises the stream): which route finished the last call on this ws
+ * (1 = single-read, 2 = full scan) and whether a grid barrier of the full scan timed out. */
+int salun_mask_topk_status(const void *ws /*dev*/, int *route_out /*host*/, int *error_out /*host*/,
+                           salun_stream_t stream);
 /* After salun_mask_topk on the same ws: copies the nk selected thresholds
  * (as fp32 |acc| values; NaN if the k-th element is a NaN; +inf for k <= 0, -1 for
  * k > n) to a device array, 4*nk bytes.  Used by the proximal step (K9) as the

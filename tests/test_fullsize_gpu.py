@@ -1,0 +1,194 @@
+"""Parity at the sizes the benchmark runs.
+
+bench.py's step is ResNet-18, batch 256 (ragged tails 148 / 52), train mode, `use_salun_convs` + `use_fused_bn`
+(BasicBlocks as single autograd nodes) + two-stream backward + `FusedMaskedSGD` with a ratio-0.5 mask.  The convolution
+dispatcher picks its tile variant from the shape alone (csrc/salun_conv.hip `launch_igemm` / `launch_dgrad_s2_merged` /
+`wgrad_nsplit`), so running the bench's own shapes here exercises exactly the instantiations the profile of the bench
+shows (`conv_igemm<3,1,2,4,1>`, `<3,1,4,4,1>`, `conv_dgrad_s2<...>`, `conv_wgrad`) — the N <= 32 cases of
+test_conv_gpu.py do not.
+
+Reference sequence: Classification/unlearn/RL.py:123-140 (`oracle/torch_ref.rl_step_cpu`), evaluated in float64 on
+the host.  Tolerances are written next to each assertion.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# the 11 distinct convolution shapes of the CIFAR ResNet-18: (C, H, K, R, stride, pad)
+RESNET18_LAYERS = [
+    (3, 32, 64, 3, 1, 1),      # stem
+    (64, 32, 64, 3, 1, 1),     # layer1.*
+    (64, 32, 128, 3, 2, 1),    # layer2.0.conv1
+    (64, 32, 128, 1, 2, 0),    # layer2.0.downsample
+    (128, 16, 128, 3, 1, 1),   # layer2.*
+    (128, 16, 256, 3, 2, 1),
+    (128, 16, 256, 1, 2, 0),
+    (256, 8, 256, 3, 1, 1),
+    (256, 8, 512, 3, 2, 1),
+    (256, 8, 512, 1, 2, 0),
+    (512, 4, 512, 3, 1, 1),
+]
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("N", [256, 148, 52])
+@pytest.mark.parametrize("C,H,K,R,stride,pad", RESNET18_LAYERS)
+def test_conv_kernels_at_the_bench_batch_sizes(N, C, H, K, R, stride, pad):
+    """Forward / backward-data / backward-weight of every ResNet-18 layer at batch 256 and at the epoch's ragged tail
+    batches (4500 % 256 = 148, 40500 % 256 = 52) against PyTorch's fp32 convolution on the host.
+    Tolerance: 1e-5 relative + 2e-5 of the tensor's scale (fp32 FMA chains in a different summation order)."""
+    from unlearn_saliency_amd import ops
+    x = _rand((N, C, H, H), 1)
+    w = _rand((K, C, R, R), 2, 0.1)
+    P = (H + 2 * pad - R) // stride + 1
+    y_ref = F.conv2d(x, w, None, stride, pad)
+    dy = _rand(tuple(y_ref.shape), 4)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    tol = lambda ref: 2e-5 * float(ref.abs().max())
+    y = ops.conv2d_forward(xd, wd, None, stride, pad, P, P)
+    assert y is not None, "a bench shape fell outside the MFMA kernels' domain"
+    assert torch.allclose(y.cpu(), y_ref, rtol=1e-5, atol=tol(y_ref))
+    dx = ops.conv2d_backward_data(dyd, wd, x.shape, stride, pad)
+    assert dx is not None and torch.allclose(dx.cpu(), dx_ref, rtol=1e-5, atol=tol(dx_ref))
+    dw = ops.conv2d_backward_weight(xd, dyd, w.shape, stride, pad)
+    # the reduction over N*P*Q = up to 262,144 terms per weight: error grows like sqrt(terms) * eps
+    assert dw is not None and torch.allclose(dw.cpu(), dw_ref, rtol=1e-5, atol=4e-5 * float(dw_ref.abs().max()))
+    assert torch.equal(dw, ops.conv2d_backward_weight(xd, dyd, w.shape, stride, pad))  # deterministic
+
+
+def _bench_models():
+    """(fast, lib): the bench's module swaps on one copy, PyTorch-ROCm library ops on the other; same init."""
+    from unlearn_saliency_amd.Classification.models import model_dict
+    from unlearn_saliency_amd.conv import use_salun_convs
+    from unlearn_saliency_amd.norm import use_fused_bn
+    torch.manual_seed(1)
+    lib = model_dict["resnet18"](num_classes=10).cuda()
+    fast = copy.deepcopy(lib)
+    assert use_salun_convs(fast) == 20 and use_fused_bn(fast) == 20
+    return fast, lib
+
+
+def test_resnet18_batch256_rl_steps_match_the_reference_sequence_in_float64():
+    """Five RL steps of the bench configuration (batch 256, train-mode BN, mask ratio 0.5, SGD 0.013 / 0.9 / 5e-4)
+    on the full fused path against the reference's op sequence evaluated in float64 on the host
+    (oracle/torch_ref.rl_step_cpu: forward, CE, backward, per-tensor mask multiply, torch.optim.SGD, per-tensor restore).
+      * masked-out weights: bit-identical to theta0 after every step; their momentum stays 0
+      * loss trajectory: |fused - f64| <= 1e-5 relative at every step (north_star)
+      * updated weights: per tensor, max |p_fused - p_f64| <= 2e-3 of that tensor's total movement max |p_f64 - theta0|
+        (the update is lr * momentum-filtered gradient; fp32 gradients of a 20-BN-layer network carry ~1e-4 relative
+        round-off, the library path — printed beside it — shows the same)."""
+    from oracle import torch_ref
+    from unlearn_saliency_amd import conv as sconv
+    from unlearn_saliency_amd import ops
+    from unlearn_saliency_amd.flat import arena_of
+    from unlearn_saliency_amd.optim import FusedMaskedSGD
+    fast, lib = _bench_models()
+    ref = copy.deepcopy(lib).cpu().double()
+    N18 = sum(p.numel() for p in fast.parameters())
+    assert N18 == 11_173_962
+    steps, bs = 5, 256
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.rand(bs, 3, 32, 32, generator=g) for _ in range(steps)]
+    ys = [torch.randint(0, 10, (bs,), generator=g) for _ in range(steps)]  # the step's random labels, fixed
+    # SalUn mask of ratio 0.5 from a synthetic saliency vector (the K2 kernel's output)
+    arena = arena_of(fast)
+    mask_u8 = ops.mask_topk(ops.fill_normal(N18, 5, 0.0, 1e-3) * (1.0 + ops.fill_uniform(N18, 6, 0.0, 0.5)), [N18 // 2])[0]
+    mask = arena.unpack_mask(mask_u8)                                   # name -> int64 0/1, the reference's artefact
+    mask_cpu = {k: v.cpu() for k, v in mask.items()}
+    theta0_flat = arena.params.clone()
+    crit = nn.CrossEntropyLoss()
+    sconv.reset_library_conv_calls()
+
+    opt_fast = FusedMaskedSGD(arena, 0.013, momentum=0.9, weight_decay=5e-4)
+    opt_fast.set_mask(mask_u8)
+    opt_lib = torch.optim.SGD(lib.parameters(), 0.013, momentum=0.9, weight_decay=5e-4)
+    opt_ref = torch.optim.SGD(ref.parameters(), 0.013, momentum=0.9, weight_decay=5e-4)
+    theta0_lib = {n: p.detach().clone() for n, p in lib.named_parameters()}
+    theta0_ref = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    mask_lib = {k: v.cuda() for k, v in mask_cpu.items()}
+    fast.train(); lib.train(); ref.train()
+    frozen = mask_u8 == 0
+    losses = {"fast": [], "lib": [], "ref": []}
+    for x, y in zip(xs, ys):
+        xd, yd = x.cuda(), y.cuda()
+        loss = crit(fast(xd), yd)
+        opt_fast.zero_grad()
+        loss.backward()
+        opt_fast.step()
+        losses["fast"].append(float(loss))
+        assert torch.equal(arena.params[frozen], theta0_flat[frozen]), "a masked-out weight moved"
+        assert not opt_fast.momentum_buffer[frozen].any(), "momentum leaked into a masked-out weight"
+        losses["lib"].append(float(torch_ref.rl_step_cpu(lib, crit, opt_lib, xd, yd, mask_lib, theta0_lib)))
+        losses["ref"].append(float(torch_ref.rl_step_cpu(ref, crit, opt_ref, x.double(), y, mask_cpu, theta0_ref)))
+    assert sconv.library_conv_calls() == 0, sconv.LIBRARY_CONV_CALLS  # every convolution ran on the MFMA kernels
+    rel = lambda a, b: abs(a - b) / abs(b)
+    e_fast = [rel(a, b) for a, b in zip(losses["fast"], losses["ref"])]
+    e_lib = [rel(a, b) for a, b in zip(losses["lib"], losses["ref"])]
+    print("loss trajectory f64:", [f"{v:.6f}" for v in losses["ref"]])
+    print("rel. deviation fused:", [f"{v:.2e}" for v in e_fast], " library fp32:", [f"{v:.2e}" for v in e_lib])
+    assert max(e_fast) <= 1e-5, e_fast
+    worst_fast = worst_lib = 0.0
+    for (n, pf), pl, pr in zip(fast.named_parameters(), lib.parameters(), ref.parameters()):
+        move = float((pr.detach() - theta0_ref[n]).abs().max())
+        if move == 0.0:
+            continue
+        worst_fast = max(worst_fast, float((pf.detach().cpu().double() - pr.detach()).abs().max()) / move)
+        worst_lib = max(worst_lib, float((pl.detach().cpu().double() - pr.detach()).abs().max()) / move)
+    print(f"weights after 5 steps, worst tensor: |p - p_f64| / |p_f64 - theta0| = fused {worst_fast:.2e}, "
+          f"library fp32 {worst_lib:.2e}")
+    assert worst_fast <= 2e-3, worst_fast
+
+
+def test_resnet18_ft_l1_step_is_ordered_with_the_side_stream():
+    """FT_l1 / GA_l1 add an l1 term whose AccumulateGrad writes every parameter's .grad on the main stream while the
+    MFMA backward-weight kernels accumulate into the same slices (a cross-stream race when those kernels run
+    on the side stream).  `run_pass` keeps them on the main stream for such steps: the flat gradient must equal the
+    library path's and be bit-identical run to run."""
+    from types import SimpleNamespace
+    from unlearn_saliency_amd.Classification.unlearn._steps import run_pass
+    from unlearn_saliency_amd.flat import arena_of
+    fast, lib = _bench_models()
+    x = torch.rand(256, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (256,), device="cuda")
+    alpha = 5e-4
+
+    class Snoop:
+        """optimizer stand-in: records the flat gradient at step() instead of updating"""
+        def __init__(self, arena):
+            self.arena, self.seen = arena, []
+            self.param_groups = [{"lr": 0.0}]
+
+        def zero_grad(self):
+            self.arena.zero_grad()
+
+        def step(self):
+            self.seen.append(self.arena.grads.clone())
+
+    arena = arena_of(fast)
+    snoop = Snoop(arena)
+    args = SimpleNamespace(warmup=0, print_freq=1000)
+    fast.train()
+    for _ in range(3):
+        run_pass([(x, y)], fast, nn.CrossEntropyLoss(), snoop, 0, args, l1_alpha=alpha, track=False)
+    torch.cuda.synchronize()
+    # BN running statistics move between the passes but do not enter the train-mode gradient
+    assert torch.equal(snoop.seen[0], snoop.seen[1]) and torch.equal(snoop.seen[0], snoop.seen[2])
+    lib.train()
+    loss = F.cross_entropy(lib(x), y) + alpha * torch.norm(torch.cat([p.view(-1) for p in lib.parameters()]), p=1)
+    loss.backward()
+    gl = torch.cat([p.grad.reshape(-1) for p in lib.parameters()])
+    gf = snoop.seen[0]
+    # the l1 part (alpha * sign(p)) is exact on both sides; the CE part differs by fp32 summation order
+    assert torch.allclose(gf, gl, rtol=1e-3, atol=2e-4 * float(gl.abs().max())), float((gf - gl).abs().max())

@@ -179,68 +179,125 @@ def test_topk_ddpm_size_property(ops, oracle_mod):
     assert tau == lo_sel
 
 
-# ----------------------------------------------------------- sampled single-pass top-k (one threshold, large N)
-def _sampled_cases(oracle_mod, n):
+# ----------------------------------------------------------- single-read route vs full scan (csrc/salun_topk.hip)
+FULL, VALUES_ONLY = 1, 2   # include/salun.h SALUN_TOPK_*
+
+
+def _route_cases(oracle_mod, n):
     from fixtures import saliency_vector_wide
-    uniq = saliency_vector_wide(n, 77)                       # almost surely unique threshold: the sampled path publishes
-    ties = oracle_mod.fill_normal(n, 5, 0, 1e-3)             # few distinct values: threshold splits a run -> full scan
+    uniq = saliency_vector_wide(n, 77)                       # almost surely unique threshold: the single-read route publishes
+    ties = oracle_mod.fill_normal(n, 5, 0, 1e-3)             # <= 786 K distinct values: every threshold sits in a run of ties
     nans = uniq.copy(); nans[::1000] = np.nan; nans[7] = np.inf
     periodic = np.tile(np.array([1e-3, 5.0, 2e-3, 7.0], np.float32), n // 4 + 1)[:n]  # four values in a fixed cycle
     ramp = (np.arange(n, dtype=np.float32) / n)              # sorted: index and rank fully correlated
     return {"unique": uniq, "ties": ties, "nans": nans, "periodic": periodic, "ramp": ramp}
 
 
-@pytest.mark.parametrize("n", [70_001, 1_000_003, N18])
-def test_topk_sampled_path_bit_exact(ops, oracle_mod, monkeypatch, n):
-    """The sampled path (forced on below its switch-over size through the test hook) returns exactly the full-scan
-    answer: published when the bracket holds and the threshold is untied (N18: 1 % candidates fit the buffer),
-    silently deferring to the full scan otherwise (small N: the bracket is wider than the candidate buffer;
-    tied thresholds; periodic data)."""
-    monkeypatch.setenv("SALUN_TOPK_SAMPLED_MIN", "1")
-    cases = _sampled_cases(oracle_mod, n)
-    plan = [(name, k) for name in cases for k in (1, 7, n // 10, n // 2, n - n // 7, n - 1)]
+def _check_tau(ops, d, acc, want):
+    tau = ops.mask_topk_thresholds(d.device, 1)[0].item()
+    sel = np.abs(acc[want.astype(bool)])
+    kth = np.nan if np.isnan(sel).any() else sel.min()
+    assert (np.isnan(tau) and np.isnan(kth)) or tau == kth, (tau, kth)
+
+
+@pytest.mark.parametrize("n", [8192, 70_001, 1_000_003, N18])
+def test_topk_single_read_route_bit_exact(ops, oracle_mod, n):
+    """Default route for n >= 8192 (sample -> brackets -> ONE pass -> exact resolution among the candidates) against
+    the oracle, one threshold per call: published by the single-read route when the threshold is resolvable among the
+    candidates (route 1), redone by the persistent full scan on the device otherwise (heavy ties, four-valued data:
+    route 2) — bit-identical masks and thresholds either way, and equal to the forced full scan."""
+    cases = _route_cases(oracle_mod, n)
+    plan = [(name, k) for name in cases for k in (1, 7, n // 10, n // 2, n - n // 7, n - 1, n)]
     if n == N18:  # the CPU oracle sorts 11 M values per call: keep the list short
-        plan = [("unique", 1), ("unique", n // 2), ("unique", n - 1), ("periodic", n // 2), ("nans", n // 3)]
+        plan = [("unique", 1), ("unique", n // 2), ("unique", n - 1), ("periodic", n // 2), ("nans", n // 3),
+                ("ties", n // 2)]
+    routes = {}
     for name, k in plan:
         acc = cases[name]
         d = dev(acc)
-        for k in (k,):
-            got = ops.mask_topk(d, [k])[0]
-            want = oracle_mod.mask_topk(acc, [k])[0]
-            assert np.array_equal(got.cpu().numpy(), want), (name, k)
-            tau = ops.mask_topk_thresholds(d.device, 1)[0].item()
-            sel = np.abs(acc[want.astype(bool)])
-            kth = np.nan if np.isnan(sel).any() else sel.min()
-            assert (np.isnan(tau) and np.isnan(kth)) or tau == kth, (name, k, tau, kth)
+        got = ops.mask_topk(d, [k])[0]
+        route, err = ops.mask_topk_status(d.device)
+        assert err == 0
+        routes.setdefault(name, set()).add(route)
+        want = oracle_mod.mask_topk(acc, [k])[0]
+        assert np.array_equal(got.cpu().numpy(), want), (name, k, route)
+        _check_tau(ops, d, acc, want)
+        full = ops.mask_topk(d, [k], flags=FULL)[0]
+        assert ops.mask_topk_status(d.device) == (2, 0)
+        assert torch.equal(full, got), (name, k)
+        _check_tau(ops, d, acc, want)
+    assert routes["unique"] == {1}, routes          # generic data never needs the fallback
+    assert 2 in routes["periodic"], routes          # 25 % of the vector ties at the threshold: candidate slabs overflow
 
 
-def test_topk_sampled_path_at_scale(ops, oracle_mod):
-    """2^26 + 3 elements (default switch-over size): popcount == k, selected >= unselected, threshold exported;
-    and the same mask as the full-scan path (hook raised above N)."""
-    import os
-    n = (1 << 26) + 3
+def test_topk_single_read_ten_thresholds_and_values_only(ops, oracle_mod):
+    """All ten ratios of the reference in one call on the single-read route; VALUES_ONLY publishes the same thresholds
+    without touching the masks."""
+    from fixtures import saliency_vector_wide
+    n = 2_000_003
+    acc = saliency_vector_wide(n, 5)
+    d = dev(acc)
+    ks = [oracle_mod.k_of(n, r / 10) for r in range(1, 11)] + [1, n - 1]
+    got = ops.mask_topk(d, ks)
+    assert ops.mask_topk_status(d.device) == (1, 0)
+    taus = ops.mask_topk_thresholds(d.device, len(ks)).cpu().numpy()
+    want = oracle_mod.mask_topk(acc, ks)
+    for k, g, w, t in zip(ks, got, want, taus):
+        assert np.array_equal(g.cpu().numpy(), w), k
+        assert t == np.abs(acc[w.astype(bool)]).min(), k
+    keep = [g.clone() for g in got]
+    assert ops.mask_topk(d, ks, flags=VALUES_ONLY) == []
+    assert ops.mask_topk_status(d.device) == (1, 0)
+    assert np.array_equal(ops.mask_topk_thresholds(d.device, len(ks)).cpu().numpy(), taus)
+    for a, b in zip(keep, got):
+        assert torch.equal(a, b)
+    ops.mask_topk(d, ks, flags=VALUES_ONLY | FULL)
+    assert ops.mask_topk_status(d.device) == (2, 0)
+    assert np.array_equal(ops.mask_topk_thresholds(d.device, len(ks)).cpu().numpy(), taus)
+
+
+def test_topk_moderate_ties_stay_on_the_single_read_route(ops, oracle_mod):
+    """A few thousand ties at the threshold (more than the exact-ranking stage holds) are ordered by flat index inside
+    k_finish (radix select on the index) without falling back."""
+    n = 3_000_000
+    acc = oracle_mod.fill_normal(n, 11, 0, 1e-3) * (1.0 + oracle_mod.fill_uniform(n, 12, 0.0, 0.5))
+    srt = np.sort(np.abs(acc))[::-1]
+    k = n // 2
+    tau = srt[k - 1]
+    rs = np.random.RandomState(0)
+    idx = rs.choice(n, 5000, replace=False)
+    acc[idx] = tau * np.where(rs.rand(5000) < 0.5, 1, -1)   # 5000 more elements exactly at the threshold
+    d = dev(acc)
+    for kk in (k, k + 1234, k + 4000):
+        got = ops.mask_topk(d, [kk])[0]
+        assert ops.mask_topk_status(d.device) == (1, 0)
+        want = oracle_mod.mask_topk(acc, [kk])[0]
+        assert np.array_equal(got.cpu().numpy(), want), kk
+        _check_tau(ops, d, acc, want)
+
+
+def test_topk_two_level_route_at_scale(ops, oracle_mod):
+    """2^27 + 3 elements: the brackets come from the exact selection on a 2^20 sample (two-level route).  popcount == k,
+    selected >= unselected, threshold exported; same mask as the full scan."""
+    n = (1 << 27) + 3
     d = ops.fill_normal(n, 123, 0.0, 1e-3) * (1.0 + ops.fill_uniform(n, 124, 0.0, 0.5))
     k = int(n * 0.5)
-    torch.cuda.synchronize()
-    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    m = ops.mask_topk(d, [k])[0]
-    t0.record(); m = ops.mask_topk(d, [k])[0]; t1.record()
-    torch.cuda.synchronize()
-    tau = ops.mask_topk_thresholds(d.device, 1)[0].item()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    res = {}
+    for i, (name, flags) in enumerate((("two-level", 0), ("full scan", FULL))):
+        m = ops.mask_topk(d, [k], flags=flags)[0]
+        ev[2 * i].record(); m = ops.mask_topk(d, [k], flags=flags)[0]; ev[2 * i + 1].record()
+        torch.cuda.synchronize()
+        route, err = ops.mask_topk_status(d.device)
+        assert err == 0 and route == (2 if flags == FULL else 1), (name, route, err)
+        res[name] = (m, ops.mask_topk_thresholds(d.device, 1)[0].item(), ev[2 * i].elapsed_time(ev[2 * i + 1]))
+    m, tau, _ = res["two-level"]
     assert ops.mask_popcount(m) == k
     a = d.abs()
     assert a[m.bool()].min().item() >= a[~m.bool()].max().item()
     assert tau == a[m.bool()].min().item()
-    os.environ["SALUN_TOPK_SAMPLED_MIN"] = str(1 << 40)
-    try:
-        t2 = torch.cuda.Event(enable_timing=True); t3 = torch.cuda.Event(enable_timing=True)
-        full = ops.mask_topk(d, [k])[0]
-        t2.record(); full = ops.mask_topk(d, [k])[0]; t3.record()
-        torch.cuda.synchronize()
-    finally:
-        del os.environ["SALUN_TOPK_SAMPLED_MIN"]
-    assert torch.equal(m, full)
-    print(f"top-k at N = 2^26+3: sampled {t0.elapsed_time(t1):.3f} ms, full scan {t2.elapsed_time(t3):.3f} ms")
+    assert torch.equal(m, res["full scan"][0]) and res["full scan"][1] == tau
+    print("top-k at N = 2^27+3: " + ", ".join(f"{k_} {v[2]:.3f} ms" for k_, v in res.items()))
 
 
 def test_mask_format_roundtrip(ops, oracle_mod):

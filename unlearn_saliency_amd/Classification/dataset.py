@@ -81,6 +81,14 @@ class BatchLoader:
         self.device = device
         self.rank, self.world_size = rank, world_size
         self._dev_cache = None  # (id(data), data_ptr-holder, targets)
+        # (lo, hi, b) of the batch just yielded: this rank holds samples [lo, hi) of a global batch of b — what the
+        # callers need to draw per-batch randomness for the GLOBAL batch (then slice) and to count-weight the loss
+        self.last_shard = None
+
+    def _slice(self, b: int):
+        if self.world_size <= 1:
+            return 0, b
+        return self.rank * b // self.world_size, (self.rank + 1) * b // self.world_size
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -116,23 +124,25 @@ class BatchLoader:
             train = self.dataset.transform == TRAIN_TRANSFORM
             for s in range(0, n, bs):
                 idx = order[s:s + bs]
-                if self.world_size > 1:  # contiguous shard of the global batch
-                    per = (idx.numel() + self.world_size - 1) // self.world_size
-                    idx = idx[self.rank * per:(self.rank + 1) * per]
-                idx = idx.contiguous()
+                b = idx.numel()
+                lo, hi = self._slice(b)  # contiguous, balanced shard of the global batch
                 crop = flip = None
                 if train:
-                    b = idx.numel()
-                    crop = torch.randint(0, 9, (b, 2), device=data.device, dtype=torch.int32)
-                    flip = (torch.rand(b, device=data.device) < 0.5).to(torch.uint8)
+                    # augmentation is drawn for the GLOBAL batch on every rank (identically seeded generators), then
+                    # sliced: ranks stay in lock-step whatever their shard sizes, and the global batch sees b
+                    # independent draws, not the same b/ws draws on every rank
+                    crop = torch.randint(0, 9, (b, 2), device=data.device, dtype=torch.int32)[lo:hi].contiguous()
+                    flip = (torch.rand(b, device=data.device) < 0.5).to(torch.uint8)[lo:hi].contiguous()
+                idx = idx[lo:hi].contiguous()
+                self.last_shard = (lo, hi, b)
                 yield ops.image_batch(data, idx, crop, flip, pad=4), targets[idx]
         else:
             order = order.tolist()
             for s in range(0, n, bs):
                 idx = order[s:s + bs]
-                if self.world_size > 1:
-                    per = (len(idx) + self.world_size - 1) // self.world_size
-                    idx = idx[self.rank * per:(self.rank + 1) * per]
+                lo, hi = self._slice(len(idx))
+                self.last_shard = (lo, hi, len(idx))
+                idx = idx[lo:hi]
                 items = [self.dataset[i] for i in idx]
                 x = torch.stack([it[0] for it in items]) if items else torch.empty(0, 3, 32, 32)
                 y = torch.tensor([it[1] for it in items], dtype=torch.int64)

@@ -50,9 +50,13 @@ def accumulate_saliency(forget_loader, model, criterion, arena=None) -> torch.Te
         n_local = image.size(0)
         scale = 1.0
         if ws > 1:
-            cnt = torch.tensor([float(n_local)], device=dev)
-            sdist.all_reduce_sum_(cnt)
-            scale = n_local / float(cnt.item())
+            sh = getattr(forget_loader, "last_shard", None)
+            if sh is not None:  # the loader knows the global batch size: no collective, no host sync
+                scale = n_local / float(sh[2])
+            else:
+                cnt = torch.tensor([float(n_local)], device=dev)
+                sdist.all_reduce_sum_(cnt)
+                scale = n_local / float(cnt.item())
         if n_local == 0:
             continue
         loss = -criterion(model(image), target)

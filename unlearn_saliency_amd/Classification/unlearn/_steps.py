@@ -16,7 +16,11 @@ from typing import Callable, Optional
 
 import torch
 
+import contextlib
+
 from .. import utils
+from ... import dist as sdist
+from ... import resblock
 
 
 def l1_regularization(model) -> torch.Tensor:
@@ -50,21 +54,39 @@ def run_pass(loader, model, criterion, optimizer, epoch: int, args, *,
     for i, (image, target) in enumerate(loader):
         if warmup_steps_per_epoch is not None and epoch < args.warmup:
             utils.warmup_lr(epoch, i + 1, optimizer, one_epoch_step=warmup_steps_per_epoch, args=args)
+        shard = getattr(loader, "last_shard", None) if sdist.world_size() > 1 else None
         if label_fn is not None:
-            target = label_fn(target)
+            if shard is not None:
+                # data parallel: the labels are drawn once per GLOBAL batch on every rank (same generator state),
+                # then sliced — the reference draws them for the whole batch (RL.py:125)
+                lo, hi, b = shard
+                target = label_fn(target.new_empty((b,) + tuple(target.shape[1:])))[lo:hi]
+            else:
+                target = label_fn(target)
         image = image.to(dev, non_blocking=True)
         target = target.to(dev, non_blocking=True)
 
+        if image.size(0) == 0:  # ragged tail smaller than the world size: contribute a zero gradient
+            optimizer.zero_grad()
+            optimizer.step()
+            if after_step is not None:
+                after_step(i + step_offset)
+            continue
         loss_target = target if batch_label_fn is None else batch_label_fn(image, target)
         output = model(image)
         loss = criterion(output, loss_target)
         if loss_sign != 1.0:
             loss = loss_sign * loss
+        if shard is not None:  # count-weight the shard mean so that AVG over ranks is the global batch mean
+            loss = loss * sdist.shard_loss_scale(loader)
         if l1_alpha:
             loss = loss + l1_alpha * l1_regularization(model)
 
         optimizer.zero_grad()
-        loss.backward()
+        # the l1 term gives every parameter a second gradient producer (AccumulateGrad on the main stream): the
+        # convolution kernels must then accumulate on the main stream too (resblock.overlap_disabled)
+        with (resblock.overlap_disabled() if l1_alpha else contextlib.nullcontext()):
+            loss.backward()
         optimizer.step()
         if after_step is not None:
             after_step(i + step_offset)

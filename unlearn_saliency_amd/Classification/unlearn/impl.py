@@ -68,12 +68,15 @@ def _iterative_unlearn_impl(unlearn_iter_func):
         if mask and not getattr(unlearn_iter_func, "_ignores_mask", False):
             optimizer.set_mask(arena.pack_mask(mask))
         scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=milestones, gamma=0.1)
-        for epoch in range(0, args.unlearn_epochs):
-            start_time = time.time()
-            print("Epoch #{}, Learning rate: {}".format(epoch, optimizer.param_groups[0]["lr"]))
-            unlearn_iter_func(data_loaders, model, criterion, optimizer, epoch, args, mask, **kwargs)
-            scheduler.step()
-            print("one epoch duration:{}".format(time.time() - start_time))
+        try:
+            for epoch in range(0, args.unlearn_epochs):
+                start_time = time.time()
+                print("Epoch #{}, Learning rate: {}".format(epoch, optimizer.param_groups[0]["lr"]))
+                unlearn_iter_func(data_loaders, model, criterion, optimizer, epoch, args, mask, **kwargs)
+                scheduler.step()
+                print("one epoch duration:{}".format(time.time() - start_time))
+        finally:
+            optimizer.close()  # drop the data-parallel gradient hooks this optimizer put on the parameters
 
     _wrapped.__name__ = getattr(unlearn_iter_func, "__name__", "unlearn")
     _wrapped.__wrapped_iter__ = unlearn_iter_func

@@ -18,6 +18,7 @@ class TensorLoader:
     def __init__(self, x, c, batch_size, shuffle=True, rank=0, world_size=1):
         self.x, self.c, self.batch_size, self.shuffle = x, c, int(batch_size), shuffle
         self.rank, self.world_size = rank, world_size
+        self.last_shard = None  # (lo, hi, b): this rank holds samples [lo, hi) of the global batch of b just yielded
 
     def __len__(self):
         return (len(self.x) + self.batch_size - 1) // self.batch_size
@@ -29,9 +30,10 @@ class TensorLoader:
         order = (torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)).to(self.x.device)
         for s in range(0, n, self.batch_size):
             idx = order[s:s + self.batch_size]
-            if self.world_size > 1:
-                lo, hi = sdist.shard_bounds(idx.numel(), self.rank, self.world_size)
-                idx = idx[lo:hi]
+            b = idx.numel()
+            lo, hi = sdist.balanced_slice(b, self.rank, self.world_size) if self.world_size > 1 else (0, b)
+            self.last_shard = (lo, hi, b)
+            idx = idx[lo:hi]
             yield self.x[idx], self.c[idx]
 
 

@@ -66,6 +66,32 @@ def antithetic_timesteps(n: int, num_timesteps: int, device) -> torch.Tensor:
     return torch.cat([t, num_timesteps - t - 1], dim=0)[:n]
 
 
+class ShardDraws:
+    """Per-batch randomness under data parallel: noise and timesteps are drawn for the GLOBAL batch on every rank
+    (identically seeded generators, like the reference's single process feeding nn.DataParallel,
+    runners/diffusion.py:124) and sliced to this rank's shard [lo, hi) — ranks consume the generators in lock-step
+    whatever their shard sizes and the global batch sees b independent draws.  Single-process: plain draws."""
+
+    def __init__(self, loader, n_local: int):
+        sh = getattr(loader, "last_shard", None) if sdist.world_size() > 1 else None
+        self.lo, self.hi, self.b = sh if sh is not None else (0, n_local, n_local)
+        assert self.hi - self.lo == n_local, (sh, n_local)
+
+    def randn_like(self, x: torch.Tensor) -> torch.Tensor:
+        if self.b == x.size(0):
+            return torch.randn_like(x)
+        return torch.randn((self.b,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)[self.lo:self.hi]
+
+    def timesteps(self, num_timesteps: int, device) -> torch.Tensor:
+        return antithetic_timesteps(self.b, num_timesteps, device)[self.lo:self.hi]
+
+    @property
+    def weight(self) -> float:
+        """shard-mean loss -> share of the global-batch mean under the AVG all-reduce of the gradients"""
+        ws = sdist.world_size()
+        return 1.0 if ws <= 1 else (self.hi - self.lo) * ws / float(self.b)
+
+
 def strip_prefix(state: dict, prefix: str = DP_PREFIX) -> "OrderedDict[str, torch.Tensor]":
     return OrderedDict((k[len(prefix):] if k.startswith(prefix) else k, v) for k, v in state.items())
 
@@ -115,8 +141,10 @@ class Diffusion(object):
         return model
 
     def _loaders(self):
-        return get_forget_dataset(self.args, self.config, self.args.label_to_forget, device=self.device,
-                                  synthetic=True if getattr(self.args, "synthetic", False) else None)
+        self._remain_loader, self._forget_loader = get_forget_dataset(
+            self.args, self.config, self.args.label_to_forget, device=self.device,
+            synthetic=True if getattr(self.args, "synthetic", False) else None)
+        return self._remain_loader, self._forget_loader
 
     # --------------------------------------------------------- Phase A: mask
     def accumulate_saliency(self, model, forget_loader, arena: FlatArena = None) -> torch.Tensor:
@@ -131,16 +159,15 @@ class Diffusion(object):
         ws = sdist.world_size()
         for x, forget_c in forget_loader:
             n = x.size(0)
+            draws = ShardDraws(forget_loader, n)
             x = data_transform(config, x.to(self.device))
-            e = torch.randn_like(x)
-            t = antithetic_timesteps(n, self.num_timesteps, self.device)
+            e = draws.randn_like(x)
+            t = draws.timesteps(self.num_timesteps, self.device)
             xt = q_sample(x, t, e, self.betas)
             output = model(xt, t.float(), forget_c, cond_scale=args.cond_scale, mode="test")
             loss = ops.eps_mse(e, output)
-            if ws > 1:  # local mean -> share of the global-batch mean
-                cnt = torch.tensor([float(n)], device=self.device)
-                sdist.all_reduce_sum_(cnt)
-                loss = loss * (n / float(cnt.item()))
+            if ws > 1:  # local mean -> share of the global-batch mean (the gradients are SUMmed below)
+                loss = loss * (n / float(draws.b))
             arena.zero_grad()
             loss.backward()
             sdist.all_reduce_sum_(arena.grads)
@@ -181,16 +208,21 @@ class Diffusion(object):
         b = self.betas
         remain_x, remain_c = remain_batch
         n = remain_x.size(0)
+        draws = ShardDraws(getattr(self, "_remain_loader", None), n)  # global-batch draws, sliced (data parallel)
         remain_x = data_transform(config, remain_x.to(self.device))
-        e = torch.randn_like(remain_x)
-        t = antithetic_timesteps(n, self.num_timesteps, self.device)
+        e = draws.randn_like(remain_x)
+        t = draws.timesteps(self.num_timesteps, self.device)
         remain_loss = loss_registry_conditional[config.model.type](model, remain_x, t, remain_c, e, b)
+        if draws.weight != 1.0:
+            remain_loss = remain_loss * draws.weight
 
         forget_x, forget_c = forget_batch
         n = forget_x.size(0)
+        draws = ShardDraws(getattr(self, "_forget_loader", None), n)
         forget_x = data_transform(config, forget_x.to(self.device))
-        e = torch.randn_like(forget_x)
-        t = antithetic_timesteps(n, self.num_timesteps, self.device)
+        e = draws.randn_like(forget_x)
+        t = draws.timesteps(self.num_timesteps, self.device)
+        forget_weight = draws.weight
         if args.method == "ga":
             forget_loss = -loss_registry_conditional[config.model.type](model, forget_x, t, forget_c, e, b)
         else:
@@ -203,6 +235,8 @@ class Diffusion(object):
                 forget_loss = ops.mse_loss(pseudo, output)
             else:
                 raise ValueError(f"unknown --method {args.method!r} (rl | ga)")
+        if forget_weight != 1.0:
+            forget_loss = forget_loss * forget_weight
         loss = forget_loss + args.alpha * remain_loss
 
         optimizer.zero_grad()

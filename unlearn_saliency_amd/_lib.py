@@ -20,6 +20,8 @@ SALUN_EINVAL = -22
 SALUN_ENOSPC = -28
 SALUN_EIO = -5
 SALUN_MAX_THRESHOLDS = 16
+SALUN_TOPK_FORCE_FULL_SCAN = 1
+SALUN_TOPK_VALUES_ONLY = 2
 
 c_void_p, c_int, c_int64, c_uint64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
 c_double, c_size_t = ctypes.c_double, ctypes.c_size_t
@@ -34,6 +36,9 @@ SIGNATURES = {
     "salun_mask_topk_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "salun_mask_topk": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_int64), c_int, ctypes.POINTER(c_void_p),
                                 c_void_p, c_size_t, c_void_p]),
+    "salun_mask_topk_ex": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_int64), c_int, ctypes.POINTER(c_void_p),
+                                   c_void_p, c_size_t, ctypes.c_uint, c_void_p]),
+    "salun_mask_topk_status": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p]),
     "salun_mask_topk_thresholds": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "salun_mask_u8_to_i64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "salun_mask_i64_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

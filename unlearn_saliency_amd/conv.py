@@ -4,7 +4,9 @@
 parameters, names and state_dict are untouched (the weights stay views of the flat arena) — so forward,
 backward-data and backward-weight run as `salun_conv2d_*` launches instead of whatever the library's
 heuristics pick for fp32 on gfx950 (`naive_conv_*` at > 1 s per ResNet-18 step on a cold
-find-db).  Shapes outside the kernels' tiling domain fall back to `F.conv2d` per call.
+find-db).  Shapes outside the kernels' tiling domain, non-fp32 inputs and autocast regions fall back to the
+library convolution per call — LOUDLY: every such call is counted in `LIBRARY_CONV_CALLS` (reported by the
+benchmarks as `library_conv_calls`), and `strict(True)` turns the fallback into an error.
 """
 from __future__ import annotations
 
@@ -14,6 +16,31 @@ import torch.nn.functional as F
 
 from . import dist as sdist
 from . import gradsink, ops, resblock
+
+
+# calls that went to the library (MIOpen) instead of the MFMA kernels, by reason
+LIBRARY_CONV_CALLS = {"shape": 0, "dtype_or_autocast": 0, "backward": 0}
+_STRICT = [False]
+
+
+def strict(on: bool = True) -> None:
+    """strict(True): a convolution that would fall back to the library raises instead."""
+    _STRICT[0] = bool(on)
+
+
+def library_conv_calls() -> int:
+    return sum(LIBRARY_CONV_CALLS.values())
+
+
+def reset_library_conv_calls() -> None:
+    for k in LIBRARY_CONV_CALLS:
+        LIBRARY_CONV_CALLS[k] = 0
+
+
+def _fallback(reason: str, what: str) -> None:
+    LIBRARY_CONV_CALLS[reason] += 1
+    if _STRICT[0]:
+        raise RuntimeError(f"salun conv: {what} would run on the library convolution ({reason}) and strict mode is on")
 
 
 def _eligible(mod: nn.Conv2d) -> bool:
@@ -28,6 +55,7 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, stride, pad, P, Q):
         y = ops.conv2d_forward(x, w, bias, stride, pad, P, Q)
         if y is None:  # outside the tiling domain
+            _fallback("shape", f"forward {tuple(x.shape)} * {tuple(w.shape)} stride {stride} pad {pad}")
             y = F.conv2d(x, w, bias, stride, pad)
             ctx.native = False
         else:
@@ -61,6 +89,7 @@ class _ConvFn(torch.autograd.Function):
             if not overlap:
                 dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad, out=dst, accumulate=True) if ctx.native else None
             if dw is None:
+                _fallback("backward", f"backward-weight {tuple(x.shape)} * {tuple(w.shape)}")
                 dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
             elif dst is not None:  # already added into w.grad by the kernel
                 gradsink.arrived(w)
@@ -68,6 +97,7 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_backward_data(dy, w, x.shape, stride, pad) if ctx.native else None
             if dx is None:
+                _fallback("backward", f"backward-data {tuple(x.shape)} * {tuple(w.shape)}")
                 dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 2, 3))
@@ -86,6 +116,7 @@ class SalunConv2d(nn.Conv2d):
             P = (x.shape[2] + 2 * p - R) // s + 1
             Q = (x.shape[3] + 2 * p - R) // s + 1
             return _ConvFn.apply(x, self.weight, self.bias, s, p, P, Q)
+        _fallback("dtype_or_autocast", f"forward of a {x.dtype} / autocast input")
         return super().forward(x)
 
 

@@ -1,26 +1,38 @@
-// salun_topk.hip — K2: global top-k saliency mask by radix select (gfx950 / CDNA4).
+// salun_topk.hip — K2: global top-k saliency mask (gfx950 / CDNA4).
 //
 // The reference ranks every weight with two full argsorts per threshold
-// (Classification/generate_mask.py:57-64) only to compare the rank with k.  Here the
-// k-th largest |acc| is located with three histogram passes over a monotone 31-bit
-// integer key (11 + 10 + 10 bit digits, most significant first), all thresholds
-// sharing every pass, and one pass writes the nk u8 masks.  Integer-only, hence
-// bit-exact and independent of launch geometry.
+// (Classification/generate_mask.py:57-64) only to compare the rank with k.  Here the k-th largest |acc| is
+// located by selection on a monotone 31-bit integer key, integer-only, hence bit-exact and independent of launch
+// geometry:
 //
-//   key(x) = 0                       if x is NaN   (ranks after every number)
-//          = (bits(x) & 0x7fffffff) + 1  otherwise (|x| as an ordered integer)
-//   mask_j[i] = 1  iff  key_i > tau_j, or key_i == tau_j and i is among the first
-//               r_j indices holding tau_j   (stable tie rule)
+//   key(x) = 0                           if x is NaN   (ranks after every number)
+//          = (bits(x) & 0x7fffffff) + 1  otherwise     (|x| as an ordered integer; the abs is fused)
+//   mask_j[i] = 1  iff  key_i > tau_j, or key_i == tau_j and i is among the first r_j indices holding tau_j
+//               (stable tie rule)
 //
-// LDS: per-workgroup histograms (u32, LDS atomics) flushed once with 64-bit global
-// atomics; pass 1/2 histograms are kept per *group* of thresholds that share the
-// already-fixed prefix, so 10 thresholds cost one read of the vector per pass.
+// Two routes, the same function of the input:
 //
-// One threshold over a large vector (N >= 2^25: the DDPM and SD masks) takes the sampled
-// single-pass route first — rank a 2^20-element sample, bracket the threshold, ONE pass
-// over the vector (final mask outside the bracket, ~1 % candidates compacted), exact
-// select among the candidates, fix-up — and falls back to the full scan on the device
-// when the bracket misses; same masks bit for bit (see k_sample ... k_sampled_finish).
+// FAST (n >= 8192, 16-B aligned input; the route of every model-sized vector) — the vector is read ONCE:
+//   k_bracket   one workgroup ranks a 16 K-element hashed sample with a two-level LDS histogram and brackets every
+//               threshold,  lo_j <= tau_j <= hi_j,  6 sigma either side of the target rank (~4.7 % of the mass)
+//   k_main      the one streaming pass: writes mask_j = [key > hi_j] (final outside the bracket), counts
+//               c_gt_j = #{key > hi_j}, compacts the in-bracket candidates (key, flat index) into per-workgroup slabs
+//   k_hist_a    histogram of the candidates over the bracket (LDS, 256..1024 bins per threshold)
+//   k_resolve   every workgroup picks the bin holding rank k_j - c_gt_j; candidates above it get their mask byte,
+//               candidates inside it go to a short list + a 4096-bin histogram of that bin
+//   k_finish    one workgroup per threshold: picks the final bin (<= a few keys wide), ranks its residents
+//               exactly (key descending, flat index ascending) and publishes tau_j
+//   For n >= 2^27 the bracket comes from an exact selection (this same route, values only) on a 2^20-element sample
+//   instead, which narrows it to ~0.6 % of the mass.
+//   Anything unusual — a bracket that misses, a slab or list that overflows (heavy ties) — raises `fail` on the
+//   device and the full scan below redoes the job; no host synchronisation anywhere.
+//
+// FULL SCAN (small or unaligned inputs, and the fallback): k_fullscan, ONE persistent launch of <= 2 workgroups per
+//   CU: three histogram passes (11 + 10 + 10 bit digits, most significant first; thresholds that share a prefix share
+//   a histogram), per-workgroup LDS histograms flushed with 64-bit global atomics, every workgroup repeating the tiny
+//   selection step itself, grid barriers between passes (monotonic counter, agent-scope release/acquire, bounded
+//   spin), per-chunk tie prefixes when a threshold splits a run of equal keys, one write pass.  When launched behind
+//   the fast route it returns at once unless `fail` is set.
 #include "salun_common.h"
 #include <cmath>
 #include <cstdlib>
@@ -29,38 +41,55 @@ namespace {
 
 constexpr int MAXK = SALUN_MAX_THRESHOLDS;
 constexpr int D0_BINS = 2048;  // key >> 20
-constexpr int D1_BINS = 1024;  // (key >> 10) & 1023
-constexpr int D2_BINS = 1024;  // key & 1023
 constexpr int CHUNK_VEC = 4 * SALUN_BLOCK;  // float4 per chunk (4 sub-vectors per lane)
-constexpr int CHUNK = CHUNK_VEC * 4;        // 4096 elements: the tie-ordering granule
-constexpr int HIST_MAX_GRID = 512;
+constexpr int CHUNK = CHUNK_VEC * 4;        // 4096 elements: streaming / tie-ordering granule
+
+constexpr int64_t FAST_MIN_N = 8192;
+constexpr int SAMPLE_MAX = 16384;             // k_bracket's sample (16 keys per thread)
+constexpr int64_t TWO_LEVEL_MIN_N = int64_t(1) << 27;
+constexpr int SAMPLE2_LOG2 = 20;              // outer sample of the two-level route
+constexpr int HIST2_BINS = 4096;
+constexpr int BINS_A_MAX = 1024;
+constexpr int FINAL_CAP = 1024;               // final-bin residents ranked exactly in LDS
+constexpr int MAIN_GRID = 1024;
+constexpr double BRACKET_SIGMAS = 6.0;
 
 enum Mode : uint32_t { MODE_NONE = 0, MODE_ALL = 1, MODE_GE = 2, MODE_ORDERED = 3 };
 
 typedef unsigned long long u64;
+typedef float vf4 __attribute__((ext_vector_type(4)));
 
-struct TopkState {
-  u64 hist0[D0_BINS];
-  u64 hist1[MAXK][D1_BINS];
-  u64 hist2[MAXK][D2_BINS];
-  long long k[MAXK];
-  u64 rem[MAXK];         // how many still to take inside the currently selected bin
-  u64 ceq[MAXK];         // population of key == tau
-  uint32_t prefix0[MAXK];
-  uint32_t prefix1[MAXK];  // 21-bit prefix (d0 << 10 | d1)
-  uint32_t tau[MAXK];
-  uint32_t mode[MAXK];
-  uint32_t group0_of[MAXK];  // threshold -> pass-1 histogram slot
-  uint32_t group1_of[MAXK];  // threshold -> pass-2 histogram slot
-  uint32_t group0_prefix[MAXK];
-  uint32_t group1_prefix[MAXK];
-  uint32_t ngroups0, ngroups1;
-  uint32_t any_ordered;
+// What salun_mask_topk_thresholds reads: first bytes of the workspace, written by whichever route finished the job.
+struct TopkPub {
   uint32_t nk;
-  uint32_t skip;           // set by the sampled path on success: the full-scan passes below return immediately
-  uint32_t use_kdev;       // take k from kdev[] (computed on the device) instead of the launch argument
-  long long kdev[MAXK];
-  uint8_t lut0[D0_BINS];  // d0 -> pass-1 slot + 1 (0 = not a boundary bin)
+  uint32_t error;        // 1: a grid barrier of the full scan timed out (results invalid)
+  uint32_t mode[MAXK];
+  uint32_t tau[MAXK];    // key of the k-th element
+  uint32_t route;        // 1 fast, 2 full scan (diagnostic)
+  uint32_t pad;
+};
+
+struct FullState {
+  u64 hist0[D0_BINS];
+  u64 hist1[MAXK][1024];
+  u64 hist2[MAXK][1024];
+  uint32_t bar;          // grid-barrier counter
+  uint32_t pad;
+};
+
+struct FastState {
+  long long k[MAXK];     // clamped to [0, n]
+  uint32_t mode[MAXK];   // MODE_NONE or MODE_GE (bracketed)
+  uint32_t was_all[MAXK];  // k > n on entry: published as MODE_ALL
+  uint32_t lo[MAXK], hi[MAXK], shiftA[MAXK];
+  u64 c_gt[MAXK];        // elements strictly above the bracket
+  uint32_t n2[MAXK];     // residents of the chosen first-level bin
+  uint32_t lo2[MAXK], hi2[MAXK], shift2[MAXK];
+  u64 r2[MAXK];          // rank wanted inside [lo2, hi2]
+  uint32_t fail;         // -> the full scan redoes the job
+  uint32_t pad;
+  uint32_t histA[MAXK][BINS_A_MAX];
+  uint32_t hist2[MAXK][HIST2_BINS];
 };
 
 struct KList {
@@ -70,107 +99,26 @@ struct KList {
 struct MaskPtrs {
   uint8_t *m[MAXK];
 };
+// explicit target ranks (descending, 1-based) in a sample, for the two-level route
+struct RankList {
+  long long hi[MAXK], lo[MAXK];  // 0 = unbounded on that side
+};
 
 __device__ __forceinline__ uint32_t key_of(float x) {
   const uint32_t b = __float_as_uint(x) & 0x7FFFFFFFu;
   return (b > 0x7F800000u) ? 0u : b + 1u;
 }
+constexpr uint32_t KEY_MAX = 0x7F800001u;   // key of +-inf: no real key is larger
 constexpr uint32_t KEY_SKIP = 0xFFFFFFFFu;  // out-of-range lane marker (never a real key)
 
-// Keys of float4 #v; elements at or beyond n become KEY_SKIP.
-template <bool ALIGNED>
-__device__ __forceinline__ void load_keys(const float *__restrict__ acc, int64_t v, int64_t n, uint32_t k[4]) {
-  const int64_t i = v << 2;
-  if (ALIGNED && i + 3 < n) {
-    const float4 x = reinterpret_cast<const float4 *>(acc)[v];
-    k[0] = key_of(x.x); k[1] = key_of(x.y); k[2] = key_of(x.z); k[3] = key_of(x.w);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) k[e] = (i + e < n) ? key_of(acc[i + e]) : KEY_SKIP;
-  }
+__device__ __forceinline__ u64 ld_agent_u64(const u64 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_agent_u32(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---------------------------------------------------------------- pass 0 histogram
-template <bool ALIGNED>
-__global__ __launch_bounds__(SALUN_BLOCK) void k_hist0(const float *__restrict__ acc, int64_t n, TopkState *st) {
-  __shared__ uint32_t h[D0_BINS];
-  if (st->skip) return;
-  for (int i = threadIdx.x; i < D0_BINS; i += SALUN_BLOCK) h[i] = 0;
-  __syncthreads();
-  const int64_t nvec = (n + 3) >> 2;
-  const int64_t nchunk = (nvec + CHUNK_VEC - 1) / CHUNK_VEC;
-  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-    uint32_t k[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
-      if (v < nvec) load_keys<ALIGNED>(acc, v, n, k[u]);
-      else k[u][0] = k[u][1] = k[u][2] = k[u][3] = KEY_SKIP;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (k[u][e] != KEY_SKIP) atomicAdd(&h[k[u][e] >> 20], 1u);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < D0_BINS; i += SALUN_BLOCK)
-    if (h[i]) atomicAdd(&st->hist0[i], (u64)h[i]);
-}
-
-// ------------------------------------------------------- pass 1 / pass 2 histograms
-// LEVEL 1: bins = d1 of keys whose d0 is a boundary bin; LEVEL 2: bins = d2 of keys
-// whose 21-bit prefix is a boundary prefix.  Dynamic LDS: lut0 (2 KiB) + nk * 1024 u32.
-template <int LEVEL, bool ALIGNED>
-__global__ __launch_bounds__(SALUN_BLOCK) void k_hist12(const float *__restrict__ acc, int64_t n, TopkState *st) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  if (st->skip) return;
-  const uint32_t ngroups = (LEVEL == 1) ? st->ngroups0 : st->ngroups1;
-  if (ngroups == 0) return;  // every threshold is trivial (k <= 0 or k >= n)
-  uint8_t *lut = reinterpret_cast<uint8_t *>(lds);  // 2048 bytes
-  uint32_t *h = lds + D0_BINS / 4;                  // ngroups (<= nk) * 1024 counters
-  __shared__ uint32_t gprefix[MAXK];
-  for (uint32_t i = threadIdx.x; i < ngroups * 1024u; i += SALUN_BLOCK) h[i] = 0;
-  for (int i = threadIdx.x; i < D0_BINS; i += SALUN_BLOCK) lut[i] = st->lut0[i];
-  if (threadIdx.x < MAXK) gprefix[threadIdx.x] = st->group1_prefix[threadIdx.x];
-  __syncthreads();
-  const int64_t nvec = (n + 3) >> 2;
-  const int64_t nchunk = (nvec + CHUNK_VEC - 1) / CHUNK_VEC;
-  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-    uint32_t k[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
-      if (v < nvec) load_keys<ALIGNED>(acc, v, n, k[u]);
-      else k[u][0] = k[u][1] = k[u][2] = k[u][3] = KEY_SKIP;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t key = k[u][e];
-        if (key == KEY_SKIP) continue;
-        const uint32_t g0 = lut[key >> 20];
-        if (!g0) continue;
-        if (LEVEL == 1) {
-          atomicAdd(&h[(g0 - 1) * 1024u + ((key >> 10) & 1023u)], 1u);
-        } else {
-          const uint32_t pre = key >> 10;
-          for (uint32_t g = 0; g < ngroups; ++g)
-            if (gprefix[g] == pre) { atomicAdd(&h[g * 1024u + (key & 1023u)], 1u); break; }
-        }
-      }
-  }
-  __syncthreads();
-  u64 *gh = (LEVEL == 1) ? &st->hist1[0][0] : &st->hist2[0][0];
-  for (uint32_t i = threadIdx.x; i < ngroups * 1024u; i += SALUN_BLOCK)
-    if (h[i]) atomicAdd(&gh[i], (u64)h[i]);
-}
-
-// -------------------------------------------------------------------- selection
-// One 1024-thread workgroup, wave w serves threshold w.  Bins are walked from the
-// top: lane l owns the l-th highest slice; a 64-lane exclusive scan of the slice
-// totals finds the slice holding the k-th element, that lane walks its bins.
+// 64-lane scans
 __device__ __forceinline__ u64 wave_excl_scan_u64(u64 v, int lane) {
   u64 inc = v;
 #pragma unroll
@@ -180,103 +128,743 @@ __device__ __forceinline__ u64 wave_excl_scan_u64(u64 v, int lane) {
   }
   return inc - v;
 }
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
 
-template <int LEVEL>
-__global__ __launch_bounds__(1024) void k_select(TopkState *st, int64_t n, KList kl) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// =====================================================================================================
+//                                              FAST ROUTE
+// =====================================================================================================
+
+// ---------------------------------------------------------------------------------- k_bracket
+// One workgroup of 1024 threads.  Zeroes the fast state, ranks a hashed sample of S keys with a 2048-bin and a
+// 256-bin LDS histogram (19 key bits: the bin edges, taken outward, only widen a bracket by ~0.05 % of the values)
+// and writes lo/hi per threshold.
+__device__ __forceinline__ uint32_t shift_for(uint32_t lo, uint32_t hi, int bins) {
+  const uint32_t w = hi - lo;
+  uint32_t s = 0;
+  while ((w >> s) >= (uint32_t)bins) ++s;
+  return s;
+}
+
+// The sample: one element per stride window at a hashed offset (a fixed offset would lock onto periodic structure of
+// the flat vector, e.g. always the centre tap of 3x3 kernels).  Spread over S/1024 workgroups: 16 K random cache lines
+// are more than one CU can pull in a few microseconds.  Writes the KEYS, coalesced.
+__global__ __launch_bounds__(1024) void k_sample(const float *__restrict__ acc, int64_t n, int S,
+                                                 uint32_t *__restrict__ keys) {
+  const int64_t stride = n / S;  // < 2^31: the offset inside a window is a 32-bit multiply-high, not a 64-bit modulo
+  const int64_t s = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  if (s < S) {
+    const uint32_t off = __umulhi((uint32_t)salun_splitmix64((uint64_t)s), (uint32_t)stride);
+    keys[s] = key_of(acc[s * stride + (int64_t)off]);
+  }
+}
+
+constexpr int H0_COPIES = 8;  // lane-indexed copies of the first-level histogram: its hot bins would serialise the
+                              // LDS atomics of a wave (a model's |gradients| sit in ~40 of the 2048 bins)
+
+__global__ __launch_bounds__(1024) void k_bracket(const uint32_t *__restrict__ keys, int64_t n, KList kl, int S, int bins_a,
+                                                  FastState *fs, TopkPub *pub, FullState *full) {
+  __shared__ uint32_t h0c[H0_COPIES][D0_BINS];
+  __shared__ uint32_t h1[2 * MAXK][256];
+  __shared__ uint8_t lut[D0_BINS];
+  __shared__ long long s_rank[2 * MAXK];   // descending rank in the sample; 0 = unbounded
+  __shared__ uint32_t s_b0[2 * MAXK], s_rem[2 * MAXK], s_grp[2 * MAXK], s_b1[2 * MAXK];
+  __shared__ uint32_t s_gprefix[2 * MAXK];
+  uint32_t *h0 = h0c[0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = kl.nk;
-  constexpr int NBINS = (LEVEL == 0) ? D0_BINS : 1024;
-  constexpr int PER_LANE = NBINS / 64;
-  if (st->skip) return;
-  __shared__ uint32_t s_bin[MAXK];
-  __shared__ u64 s_rem[MAXK];
-  __shared__ u64 s_cnt[MAXK];
-  if (LEVEL == 0 && threadIdx.x < MAXK) {
-    uint32_t mode = MODE_NONE;
-    long long k = 0;
-    if ((int)threadIdx.x < nk) {
-      k = st->use_kdev ? st->kdev[threadIdx.x] : kl.k[threadIdx.x];
-      if (k <= 0) { k = 0; mode = MODE_NONE; }
-      else if (k > n) { k = n; mode = MODE_ALL; }  // k == n runs the select: its threshold (the minimum) is real
-      else mode = MODE_GE;  // provisional: refined after the last level
+  // ---- zero the small head of the state (the histograms are zeroed by k_main's workgroups)
+  {
+    uint32_t *z = reinterpret_cast<uint32_t *>(fs);
+    const int words_head = (int)(offsetof(FastState, histA) / 4);
+    for (int i = tid; i < words_head; i += 1024) z[i] = 0;
+    if (tid == 0) { full->bar = 0; pub->nk = (uint32_t)nk; pub->error = 0; pub->route = 0; }
+  }
+  for (int i = tid; i < H0_COPIES * D0_BINS; i += 1024) (&h0c[0][0])[i] = 0;
+  for (int i = tid; i < D0_BINS; i += 1024) lut[i] = 0;
+  for (int i = tid; i < 2 * MAXK * 256; i += 1024) (&h1[0][0])[i] = 0;
+  // ---- target ranks
+  if (tid < nk) {
+    long long k = kl.k[tid];
+    if (k > n) k = n;
+    long long rhi = 0, rlo = 0;
+    if (k > 0) {
+      const double p = (double)k / (double)n;
+      const double sigma = sqrt((double)S * p * (1.0 - p));
+      const long long margin = (long long)ceil(BRACKET_SIGMAS * sigma) + 8;
+      const long long rho = llround(p * (double)S);
+      rhi = rho - margin;  // larger keys: smaller descending rank
+      rlo = rho + margin;
+      if (rhi < 1) rhi = 0;
+      if (rlo > S) rlo = 0;
     }
-    st->k[threadIdx.x] = k;
-    st->mode[threadIdx.x] = mode;
-    st->rem[threadIdx.x] = (u64)k;
-    if (threadIdx.x == 0) st->nk = nk;
+    s_rank[2 * tid] = rhi;
+    s_rank[2 * tid + 1] = rlo;
+  }
+  const int per = S >> 10;  // 4 .. 16 keys per thread
+  uint32_t key[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) key[i] = (i < per) ? keys[i * 1024 + tid] : KEY_SKIP;
+  __syncthreads();
+  {
+    uint32_t *mine = h0c[lane & (H0_COPIES - 1)];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (key[i] != KEY_SKIP) atomicAdd(&mine[key[i] >> 20], 1u);
   }
   __syncthreads();
-  if (wave < nk) {
-    const uint32_t mode = st->mode[wave];
-    if (mode >= MODE_GE) {
-      const u64 *hist = (LEVEL == 0) ? st->hist0
-                        : (LEVEL == 1) ? st->hist1[st->group0_of[wave]]
-                                       : st->hist2[st->group1_of[wave]];
-      const u64 want = st->rem[wave];  // 1 <= want <= population of this histogram
-      u64 mine = 0;
-      for (int j = 0; j < PER_LANE; ++j) mine += hist[NBINS - 1 - (lane * PER_LANE + j)];
-      const u64 before = wave_excl_scan_u64(mine, lane);
-      if (before < want && want <= before + mine) {
+  for (int i = tid; i < D0_BINS; i += 1024) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int c = 0; c < H0_COPIES; ++c) t += h0c[c][i];
+    h0[i] = t;  // copy 0 becomes the total (each thread touches only its own bins)
+  }
+  __syncthreads();
+  // ---- level 0: wave w serves ranks w, w + 16 (bins walked from the top, lane l owns 32 bins)
+  for (int q = wave; q < 2 * nk; q += 16) {
+    const long long want = s_rank[q];
+    if (want == 0) continue;
+    uint32_t mine = 0;
+    for (int j = 0; j < 32; ++j) mine += h0[D0_BINS - 1 - (lane * 32 + j)];
+    const uint32_t incl = wave_incl_scan_u32(mine, lane);
+    const uint32_t before = incl - mine;
+    if ((long long)before < want && want <= (long long)incl) {
+      uint32_t cum = before;
+      for (int j = 0; j < 32; ++j) {
+        const int bin = D0_BINS - 1 - (lane * 32 + j);
+        const uint32_t c = h0[bin];
+        if (want <= (long long)(cum + c)) { s_b0[q] = (uint32_t)bin; s_rem[q] = (uint32_t)(want - cum); break; }
+        cum += c;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t ng = 0;
+    for (int q = 0; q < 2 * nk; ++q) {
+      if (s_rank[q] == 0) continue;
+      uint32_t g = 0;
+      for (; g < ng; ++g) if (s_gprefix[g] == s_b0[q]) break;
+      if (g == ng) { s_gprefix[ng] = s_b0[q]; lut[s_b0[q]] = (uint8_t)(ng + 1); ++ng; }
+      s_grp[q] = g;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (key[i] != KEY_SKIP) {
+      const uint32_t g = lut[key[i] >> 20];
+      if (g) atomicAdd(&h1[g - 1][(key[i] >> 12) & 255u], 1u);
+    }
+  __syncthreads();
+  // ---- level 1: 256 bins, lane owns 4
+  for (int q = wave; q < 2 * nk; q += 16) {
+    if (s_rank[q] == 0) continue;
+    const uint32_t *h = h1[s_grp[q]];
+    const uint32_t want = s_rem[q];
+    uint32_t mine = 0;
+    for (int j = 0; j < 4; ++j) mine += h[255 - (lane * 4 + j)];
+    const uint32_t incl = wave_incl_scan_u32(mine, lane);
+    const uint32_t before = incl - mine;
+    if (before < want && want <= incl) {
+      uint32_t cum = before;
+      for (int j = 0; j < 4; ++j) {
+        const int bin = 255 - (lane * 4 + j);
+        const uint32_t c = h[bin];
+        if (want <= cum + c) { s_b1[q] = (uint32_t)bin; break; }
+        cum += c;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nk) {
+    long long k = kl.k[tid];
+    if (k > n) k = n;
+    uint32_t lo, hi, mode;
+    if (k <= 0) {
+      k = 0; mode = MODE_NONE; lo = hi = KEY_SKIP;  // nothing is above, nothing is inside
+    } else {
+      mode = MODE_GE;
+      hi = s_rank[2 * tid] ? ((s_b0[2 * tid] << 20) | (s_b1[2 * tid] << 12) | 0xFFFu) : KEY_MAX;
+      lo = s_rank[2 * tid + 1] ? ((s_b0[2 * tid + 1] << 20) | (s_b1[2 * tid + 1] << 12)) : 0u;
+      if (hi > KEY_MAX) hi = KEY_MAX;
+    }
+    fs->k[tid] = k;
+    fs->mode[tid] = mode;
+    fs->was_all[tid] = kl.k[tid] > n ? 1u : 0u;
+    fs->lo[tid] = lo;
+    fs->hi[tid] = hi;
+    fs->shiftA[tid] = (mode == MODE_GE) ? shift_for(lo, hi, bins_a) : 0;
+  }
+}
+
+// Two-level route: the brackets are exact order statistics of the 2^20-element sample (published by the inner
+// selection as thresholds 2j = upper, 2j+1 = lower).
+__global__ __launch_bounds__(1024) void k_bracket_from_inner(const TopkPub *inner, int64_t n, KList kl, RankList rl,
+                                                             int bins_a, FastState *fs, TopkPub *pub, FullState *full) {
+  const int tid = threadIdx.x;
+  const int nk = kl.nk;
+  uint32_t *z = reinterpret_cast<uint32_t *>(fs);
+  const int words_head = (int)(offsetof(FastState, histA) / 4);
+  for (int i = tid; i < words_head; i += 1024) z[i] = 0;
+  if (tid == 0) { full->bar = 0; pub->nk = (uint32_t)nk; pub->error = inner->error; pub->route = 0; }
+  __syncthreads();
+  if (tid < nk) {
+    long long k = kl.k[tid];
+    if (k > n) k = n;
+    uint32_t lo, hi, mode;
+    if (k <= 0) {
+      k = 0; mode = MODE_NONE; lo = hi = KEY_SKIP;
+    } else {
+      mode = MODE_GE;
+      hi = rl.hi[tid] ? inner->tau[2 * tid] : KEY_MAX;
+      lo = rl.lo[tid] ? inner->tau[2 * tid + 1] : 0u;
+      if (hi > KEY_MAX) hi = KEY_MAX;
+      if (lo > hi) lo = hi;  // cannot happen for a valid inner selection; keeps the arithmetic below in range
+    }
+    fs->k[tid] = k;
+    fs->mode[tid] = mode;
+    fs->was_all[tid] = kl.k[tid] > n ? 1u : 0u;
+    fs->lo[tid] = lo;
+    fs->hi[tid] = hi;
+    fs->shiftA[tid] = (mode == MODE_GE) ? shift_for(lo, hi, bins_a) : 0;
+  }
+}
+
+__global__ __launch_bounds__(SALUN_BLOCK) void k_gather_sample(const float *__restrict__ acc, int64_t stride, int64_t S,
+                                                               float *__restrict__ out) {
+  const int64_t s = (int64_t)blockIdx.x * SALUN_BLOCK + threadIdx.x;
+  if (s < S) out[s] = acc[s * stride + (int64_t)__umulhi((uint32_t)salun_splitmix64((uint64_t)s ^ 0x5bd1e995ull),
+                                                         (uint32_t)stride)];
+}
+
+// -------------------------------------------------------------------------------------- k_main
+// The one streaming pass.  Chunk c = 4096 elements; lane t, sub-vector u touches float4 #(c*1024 + u*256 + t), so a
+// wave instruction covers a contiguous 1 KiB and the mask goes out as one dword per float4.  Candidates are
+// compacted slot by slot: the ballot of "lane holds a candidate in slot (u, e)" gives every lane its offset
+// (mbcnt) with no scan, one LDS atomic per wave and chunk reserves the slab range, empty slots are skipped by a
+// scalar branch.  No same-address global atomics anywhere (each costs ~12 ns at the memory side and they serialise):
+// per-workgroup counts go to plain rows that the next kernel sums.
+template <int NK, bool VO>
+__global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ acc, int64_t n, FastState *fs,
+                                                      MaskPtrs mp, uint2 *__restrict__ slabs,
+                                                      uint32_t *__restrict__ slab_cnt, uint32_t *__restrict__ wg_gt,
+                                                      uint32_t cap, int nk_real, int bins_a) {
+  __shared__ uint32_t s_cnt[NK];
+  __shared__ uint32_t s_gt[4][NK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < NK) s_cnt[tid] = 0;
+  {  // this workgroup's share of zeroing the histograms k_hist_a / k_resolve accumulate into
+    const int wa = nk_real * BINS_A_MAX, w2 = nk_real * HIST2_BINS;
+    uint32_t *za = &fs->histA[0][0], *z2 = &fs->hist2[0][0];
+    for (int i = blockIdx.x * SALUN_BLOCK + tid; i < wa + w2; i += gridDim.x * SALUN_BLOCK) {
+      if (i < wa) za[i] = 0; else z2[i - wa] = 0;
+    }
+  }
+  uint32_t hi[NK], lo[NK], gtc[NK];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    hi[j] = (j < nk_real) ? fs->hi[j] : KEY_SKIP;
+    lo[j] = (j < nk_real) ? fs->lo[j] : KEY_SKIP;
+    gtc[j] = 0;
+  }
+  __syncthreads();
+  const int64_t nfull = n / CHUNK;
+  for (int64_t c = blockIdx.x; c < nfull; c += gridDim.x) {
+    uint32_t k[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // read exactly once: non-temporal
+      const vf4 x = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(acc) + c * CHUNK_VEC + u * SALUN_BLOCK + tid);
+      k[u][0] = key_of(x.x); k[u][1] = key_of(x.y); k[u][2] = key_of(x.z); k[u][3] = key_of(x.w);
+    }
+    const uint32_t idx0 = (uint32_t)((c * CHUNK_VEC + tid) << 2);  // flat index of slot (u, e): idx0 + u*1024 + e
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      if (j >= nk_real) continue;  // NK is the instantiated size >= nk_real (uniform)
+      const uint32_t w = hi[j] - lo[j];
+      unsigned long long bal[16];
+      uint32_t total = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bits |= (uint32_t)(k[u][e] > hi[j]) << (8 * e);
+          bal[u * 4 + e] = __builtin_amdgcn_ballot_w64((k[u][e] - lo[j]) <= w);
+          total += (uint32_t)__builtin_popcountll(bal[u * 4 + e]);
+        }
+        gtc[j] += (uint32_t)__builtin_popcount(bits);
+        if (!VO)
+          __builtin_nontemporal_store(bits, reinterpret_cast<uint32_t *>(mp.m[j]) + c * CHUNK_VEC + u * SALUN_BLOCK + tid);
+      }
+      if (total) {  // wave-uniform
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt[j], total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        uint2 *slab = slabs + ((size_t)blockIdx.x * (size_t)nk_real + (size_t)j) * cap;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned long long b = bal[u * 4 + e];
+            if (b) {  // scalar branch: most slots hold no candidate when the bracket is narrow
+              if ((b >> lane) & 1ull) {
+                const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                if (pos < cap) slab[pos] = make_uint2(k[u][e], idx0 + (uint32_t)(u * 1024 + e));
+              }
+              base += (uint32_t)__builtin_popcountll(b);
+            }
+          }
+      }
+    }
+  }
+  // ragged tail (n % 4096 elements): one workgroup, element-wise
+  if ((int64_t)blockIdx.x == nfull % (int64_t)gridDim.x) {
+    for (int64_t i = nfull * CHUNK + tid; i < n; i += SALUN_BLOCK) {
+      const uint32_t key = key_of(acc[i]);
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        if (j >= nk_real) continue;
+        const uint32_t gt = key > hi[j];
+        gtc[j] += gt;
+        if (!VO) mp.m[j][i] = (uint8_t)gt;
+        if ((key - lo[j]) <= (hi[j] - lo[j])) {
+          const uint32_t pos = atomicAdd(&s_cnt[j], 1u);
+          if (pos < cap)
+            slabs[((size_t)blockIdx.x * (size_t)nk_real + (size_t)j) * cap + pos] = make_uint2(key, (uint32_t)i);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    uint32_t v = gtc[j];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) s_gt[wave][j] = v;
+  }
+  __syncthreads();
+  if (tid < nk_real) {
+    wg_gt[(size_t)blockIdx.x * nk_real + tid] = s_gt[0][tid] + s_gt[1][tid] + s_gt[2][tid] + s_gt[3][tid];
+    const uint32_t mine = s_cnt[tid];
+    slab_cnt[(size_t)blockIdx.x * nk_real + tid] = mine < cap ? mine : cap;
+    if (mine > cap) fs->fail = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------ k_hist_a
+// Histogram of the compacted candidates over their bracket, one wave per slab row (no serial chain of dependent
+// loads inside a workgroup).  Dynamic LDS: nk * bins_a counters.  Workgroups 0..nk-1 also sum the per-workgroup
+// "above the bracket" counts of k_main into c_gt.
+__global__ __launch_bounds__(1024) void k_hist_a(FastState *fs, const uint2 *__restrict__ slabs,
+                                                 const uint32_t *__restrict__ slab_cnt,
+                                                 const uint32_t *__restrict__ wg_gt, uint32_t cap, int main_grid, int nk,
+                                                 int bins_a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ u64 s_red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < nk * bins_a; i += 1024) lds[i] = 0;
+  __syncthreads();
+  const int rows = main_grid * nk;
+  const int waves = gridDim.x * 16;
+  const int spr = waves > rows ? waves / rows : 1;  // waves sharing one row when there are more waves than rows
+  for (int w = blockIdx.x * 16 + wave; w < rows * spr; w += waves) {
+    const int r = w / spr, part = w % spr;
+    const int j = r % nk;
+    const uint32_t cnt = slab_cnt[r];
+    const uint32_t lo = fs->lo[j], sh = fs->shiftA[j];
+    const uint2 *slab = slabs + (size_t)r * cap;
+    uint32_t *h = lds + j * bins_a;
+    for (uint32_t i = part * 64 + lane; i < cnt; i += 64 * spr) atomicAdd(&h[(slab[i].x - lo) >> sh], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < nk * bins_a; i += 1024)
+    if (lds[i]) atomicAdd(&fs->histA[i / bins_a][i % bins_a], lds[i]);
+  if ((int)blockIdx.x < nk) {
+    const int j = blockIdx.x;
+    u64 v = 0;
+    for (int b = tid; b < main_grid; b += 1024) v += wg_gt[(size_t)b * nk + j];
+    v = salun_wave_sum_u64(v);
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      u64 t = 0;
+      for (int w = 0; w < 16; ++w) t += s_red[w];
+      fs->c_gt[j] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ k_resolve
+// Every workgroup repeats the tiny first-level selection (wave w serves threshold w), then its waves walk slab rows
+// (one wave per row): candidates above the chosen bin are selected for good, candidates inside it are counted in a
+// 4096-bin histogram of that bin (global atomics spread over 4096 addresses) and staged in LDS; each workgroup owns a
+// private segment of the threshold's short list and a plain count, so nothing is appended through a shared counter.
+constexpr int STAGE_CAP = 1024;
+
+template <bool VO>
+__global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__restrict__ slabs,
+                                                  const uint32_t *__restrict__ slab_cnt, uint32_t cap, int main_grid,
+                                                  int nk, int bins_a, int nseg, uint2 *__restrict__ list2 /*[nk][nseg][STAGE_CAP]*/,
+                                                  uint32_t *__restrict__ seg_cnt /*[nk][nseg]*/, MaskPtrs mp) {
+  __shared__ uint32_t s_lo2, s_hi2, s_sh2, s_ok;
+  __shared__ uint2 s_stage[STAGE_CAP];
+  __shared__ uint32_t s_n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = blockIdx.x % nk, g = blockIdx.x / nk;  // workgroup g of the nseg that serve threshold j
+  if (tid == 0) { s_n = 0; s_ok = 0; }
+  __syncthreads();
+  if (wave == 0 && fs->mode[j] == MODE_GE) {
+    const long long r = fs->k[j] - (long long)fs->c_gt[j];  // rank wanted among the candidates, 1-based descending
+    const uint32_t *h = fs->histA[j];
+    const int per = bins_a / 64;
+    u64 mine = 0;
+    for (int i = 0; i < per; ++i) mine += h[bins_a - 1 - (lane * per + i)];
+    const u64 before = wave_excl_scan_u64(mine, lane);
+    const u64 total = __shfl(before + mine, 63, 64);
+    if (r >= 1 && (u64)r <= total) {
+      if (before < (u64)r && (u64)r <= before + mine) {
         u64 cum = before;
-        for (int j = 0; j < PER_LANE; ++j) {
-          const int bin = NBINS - 1 - (lane * PER_LANE + j);
-          const u64 c = hist[bin];
-          if (want <= cum + c) {
-            s_bin[wave] = (uint32_t)bin;
-            s_rem[wave] = want - cum;
-            s_cnt[wave] = c;
+        for (int i = 0; i < per; ++i) {
+          const int bin = bins_a - 1 - (lane * per + i);
+          const u64 c = h[bin];
+          if ((u64)r <= cum + c) {
+            const uint32_t sh = fs->shiftA[j];
+            const uint32_t lo2 = fs->lo[j] + ((uint32_t)bin << sh);
+            uint32_t hi2 = lo2 + ((1u << sh) - 1u);
+            if (hi2 > fs->hi[j] || hi2 < lo2) hi2 = fs->hi[j];
+            s_lo2 = lo2; s_hi2 = hi2; s_sh2 = sh > 12 ? sh - 12 : 0; s_ok = 1;
+            if (g == 0) {
+              fs->lo2[j] = lo2; fs->hi2[j] = hi2; fs->shift2[j] = sh > 12 ? sh - 12 : 0;
+              fs->r2[j] = (u64)r - cum;
+            }
             break;
           }
           cum += c;
         }
       }
+    } else if (g == 0 && lane == 0) {
+      fs->fail = 1;  // the bracket missed the threshold
     }
   }
   __syncthreads();
-  // Publish + group thresholds that fell into the same bin (they share the next histogram).
-  if (threadIdx.x == 0) {
-    uint32_t ng = 0, any_ordered = 0;
-    for (int i = 0; i < nk; ++i) {
-      if (st->mode[i] < MODE_GE) continue;
-      st->rem[i] = s_rem[i];
-      if (LEVEL == 0) {
-        st->prefix0[i] = s_bin[i];
-        uint32_t g = 0;
-        for (; g < ng; ++g) if (st->group0_prefix[g] == s_bin[i]) break;
-        if (g == ng) st->group0_prefix[ng++] = s_bin[i];
-        st->group0_of[i] = g;
-      } else if (LEVEL == 1) {
-        const uint32_t pre = (st->prefix0[i] << 10) | s_bin[i];
-        st->prefix1[i] = pre;
-        uint32_t g = 0;
-        for (; g < ng; ++g) if (st->group1_prefix[g] == pre) break;
-        if (g == ng) st->group1_prefix[ng++] = pre;
-        st->group1_of[i] = g;
-      } else {
-        st->tau[i] = (st->prefix1[i] << 10) | s_bin[i];
-        st->ceq[i] = s_cnt[i];
-        if (s_rem[i] != s_cnt[i]) { st->mode[i] = MODE_ORDERED; any_ordered = 1; }
+  if (s_ok) {
+    const uint32_t lo2 = s_lo2, hi2 = s_hi2, sh2 = s_sh2;
+    uint8_t *mask = mp.m[j];
+    const int waves = nseg * 16;
+    const int spr = waves > main_grid ? waves / main_grid : 1;  // waves sharing one slab row
+    for (int w = g * 16 + wave; w < main_grid * spr; w += waves) {
+      const int b = w / spr, part = w % spr;
+      const size_t r = (size_t)b * nk + j;
+      const uint32_t cnt = slab_cnt[r];
+      const uint2 *slab = slabs + r * cap;
+      for (uint32_t i = part * 64 + lane; i < cnt; i += 64 * spr) {
+        const uint2 e = slab[i];
+        if (e.x > hi2) { if (!VO) mask[e.y] = 1; }
+        else if (e.x >= lo2) {
+          atomicAdd(&fs->hist2[j][(e.x - lo2) >> sh2], 1u);
+          const uint32_t p = atomicAdd(&s_n, 1u);
+          if (p < (uint32_t)STAGE_CAP) s_stage[p] = e;
+        }
       }
     }
-    if (LEVEL == 0) st->ngroups0 = ng;
-    if (LEVEL == 1) st->ngroups1 = ng;
-    if (LEVEL == 2) st->any_ordered = any_ordered;
   }
-  if (LEVEL == 0) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < D0_BINS; i += 1024) st->lut0[i] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t ng = st->ngroups0;
-      for (uint32_t g = 0; g < ng; ++g) st->lut0[st->group0_prefix[g]] = (uint8_t)(g + 1);
-    }
+  __syncthreads();
+  const uint32_t m = s_n;
+  const uint32_t keep = m < (uint32_t)STAGE_CAP ? m : (uint32_t)STAGE_CAP;
+  uint2 *seg = list2 + ((size_t)j * nseg + g) * STAGE_CAP;
+  for (uint32_t q = tid; q < keep; q += 1024) seg[q] = s_stage[q];
+  if (tid == 0) {
+    seg_cnt[(size_t)j * nseg + g] = keep;
+    if (m > (uint32_t)STAGE_CAP) fs->fail = 1;  // more residents than this workgroup's segment holds (heavy ties)
   }
 }
 
-// ------------------------------------------------------- ordered ties (rare path)
-// Only when some threshold splits a run of equal keys: per-chunk populations of
-// key == tau, exclusive-scanned over chunks, give every chunk the number of equal
-// keys that precede it in flat-index order.
+// ------------------------------------------------------------------------------------- k_finish
+// One workgroup (1024 threads) per threshold.
+__device__ __forceinline__ uint32_t block1024_excl_scan(uint32_t v, uint32_t *s_w /*16*/, uint32_t *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan_u32(v, lane);
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wave) woff += s_w[w]; tot += s_w[w]; }
+  *total = tot;
+  __syncthreads();
+  return woff + incl - v;
+}
+
+constexpr int MAX_SEGS = 1024;  // k_resolve grid bound
+
+// entry #f of the concatenated segments: segment by binary search over the exclusive offsets
+__device__ __forceinline__ uint2 list_entry(const uint2 *__restrict__ lst, const uint32_t *s_off, int nseg, uint32_t f) {
+  int a = 0, b = nseg - 1;
+  while (a < b) {
+    const int mid = (a + b + 1) >> 1;
+    if (s_off[mid] <= f) a = mid; else b = mid - 1;
+  }
+  return lst[(size_t)a * STAGE_CAP + (f - s_off[a])];
+}
+
+template <bool VO>
+__global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, const uint2 *__restrict__ list2,
+                                                 const uint32_t *__restrict__ seg_cnt, int nseg, MaskPtrs mp) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_off[MAX_SEGS];
+  __shared__ uint32_t s_key[FINAL_CAP], s_idx[FINAL_CAP];
+  __shared__ uint32_t s_b2, s_r3, s_c3, s_found, s_n, s_tau, s_hist[2048], s_sel, s_rem;
+  const int j = blockIdx.x, tid = threadIdx.x;
+  if (fs->fail) return;  // the full scan publishes
+  const uint32_t mode = fs->mode[j];
+  if (mode != MODE_GE) {
+    if (tid == 0) { pub->mode[j] = MODE_NONE; pub->tau[j] = 0; pub->route = 1; }
+    return;
+  }
+  const u64 r2 = fs->r2[j];
+  const uint32_t lo2 = fs->lo2[j], hi2 = fs->hi2[j], sh2 = fs->shift2[j];
+  if (tid == 0) { s_found = 0; s_n = 0; s_tau = 0; }
+  uint32_t n2;
+  {  // offsets of the per-workgroup segments of the short list
+    const uint32_t c = (tid < nseg) ? seg_cnt[(size_t)j * nseg + tid] : 0;
+    const uint32_t ex = block1024_excl_scan(c, s_w, &n2);
+    if (tid < nseg) s_off[tid] = ex;
+  }
+  __syncthreads();
+  // ---- final bin: 4096 bins walked from the top, thread t owns bins 4095-4t .. 4095-4t-3
+  {
+    const uint32_t *h = fs->hist2[j];
+    uint32_t c[4], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[i] = h[HIST2_BINS - 1 - (tid * 4 + i)]; mine += c[i]; }
+    uint32_t total;
+    const uint32_t before = block1024_excl_scan(mine, s_w, &total);
+    if ((u64)total != (u64)n2 || r2 < 1 || r2 > (u64)total) {
+      if (tid == 0) fs->fail = 1;
+      return;
+    }
+    if ((u64)before < r2 && r2 <= (u64)before + mine) {
+      uint32_t cum = before;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!s_found && r2 <= (u64)cum + c[i]) {
+          s_b2 = HIST2_BINS - 1 - (tid * 4 + i);
+          s_r3 = (uint32_t)(r2 - cum);
+          s_c3 = c[i];
+          s_found = 1;
+        }
+        cum += c[i];
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t lo3 = lo2 + (s_b2 << sh2);
+  uint32_t hi3 = lo3 + ((1u << sh2) - 1u);
+  if (hi3 > hi2 || hi3 < lo3) hi3 = hi2;
+  const uint32_t r3 = s_r3, c3 = s_c3;
+  const uint2 *lst = list2 + (size_t)j * nseg * STAGE_CAP;
+  uint8_t *mask = mp.m[j];
+  const uint32_t all_mode = fs->was_all[j] ? MODE_ALL : MODE_GE;
+  if (c3 <= (uint32_t)FINAL_CAP) {
+    for (uint32_t f = tid; f < n2; f += 1024) {
+      const uint2 e = list_entry(lst, s_off, nseg, f);
+      if (e.x > hi3) { if (!VO) mask[e.y] = 1; }
+      else if (e.x >= lo3) {
+        const uint32_t p = atomicAdd(&s_n, 1u);
+        if (p < (uint32_t)FINAL_CAP) { s_key[p] = e.x; s_idx[p] = e.y; }
+      }
+    }
+    __syncthreads();
+    const uint32_t L = s_n;
+    if (L != c3) { if (tid == 0) fs->fail = 1; return; }
+    for (uint32_t p = tid; p < L; p += 1024) {
+      const uint32_t kp = s_key[p], ip = s_idx[p];
+      uint32_t rank = 0;
+      for (uint32_t q = 0; q < L; ++q) rank += (s_key[q] > kp) || (s_key[q] == kp && s_idx[q] < ip);
+      if (rank < r3 && !VO) mask[ip] = 1;
+      if (rank == r3 - 1) s_tau = kp;
+    }
+    __syncthreads();
+    if (tid == 0) { pub->mode[j] = all_mode; pub->tau[j] = s_tau; pub->route = 1; }
+    return;
+  }
+  if (sh2 != 0) {  // a crowded final bin that still spans several keys: not worth a fourth level here
+    if (tid == 0) fs->fail = 1;
+    return;
+  }
+  // ---- more than FINAL_CAP entries tie at the single key lo3: admit the r3 lowest flat indices.  Radix select
+  // on the index (11 + 11 + 10 bits, most significant first, ascending) over the short list.
+  uint32_t prefix = 0, want = r3;
+  for (int level = 0; level < 3; ++level) {
+    const int shift = (level == 0) ? 21 : (level == 1) ? 10 : 0;
+    const int nb = (level == 2) ? 1024 : 2048;
+    for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    for (uint32_t f = tid; f < n2; f += 1024) {
+      const uint2 e = list_entry(lst, s_off, nseg, f);
+      if (e.x != lo3) continue;
+      const bool match = (level == 0) || (level == 1 ? (e.y >> 21) == prefix : (e.y >> 10) == prefix);
+      if (match) atomicAdd(&s_hist[(e.y >> shift) & (uint32_t)(nb - 1)], 1u);
+    }
+    __syncthreads();
+    const uint32_t a = s_hist[2 * tid], b = s_hist[2 * tid + 1];  // ascending bins (bins >= nb stay zero)
+    uint32_t total;
+    const uint32_t before = block1024_excl_scan(a + b, s_w, &total);
+    if (before < want && want <= before + a + b) {
+      if (want <= before + a) { s_sel = 2 * tid; s_rem = want - before; }
+      else { s_sel = 2 * tid + 1; s_rem = want - before - a; }
+    }
+    __syncthreads();
+    prefix = (level == 0) ? s_sel : (level == 1) ? ((prefix << 11) | s_sel) : ((prefix << 10) | s_sel);
+    want = s_rem;
+    __syncthreads();
+  }
+  const uint32_t idx_star = prefix;  // the r3-th lowest index among the ties
+  if (!VO)
+    for (uint32_t f = tid; f < n2; f += 1024) {
+      const uint2 e = list_entry(lst, s_off, nseg, f);
+      if (e.x > hi3 || (e.x == lo3 && e.y <= idx_star)) mask[e.y] = 1;
+    }
+  if (tid == 0) { pub->mode[j] = all_mode; pub->tau[j] = lo3; pub->route = 1; }
+}
+
+// =====================================================================================================
+//                                              FULL SCAN
+// =====================================================================================================
+struct Sel {  // selection state, one copy per workgroup (every workgroup repeats the selection)
+  long long k[MAXK];
+  u64 rem[MAXK];
+  u64 ceq[MAXK];
+  uint32_t prefix0[MAXK], prefix1[MAXK], tau[MAXK], mode[MAXK];
+  uint32_t group0_of[MAXK], group1_of[MAXK], group0_prefix[MAXK], group1_prefix[MAXK];
+  uint32_t ngroups0, ngroups1, any_ordered, nk;
+  uint32_t bin[MAXK];
+  u64 brem[MAXK], bcnt[MAXK];
+};
+
+__device__ __forceinline__ void load_keys(const float *__restrict__ acc, int64_t v, int64_t n, bool aligned,
+                                          uint32_t k[4]) {
+  const int64_t i = v << 2;
+  if (aligned && i + 3 < n) {
+    const float4 x = reinterpret_cast<const float4 *>(acc)[v];
+    k[0] = key_of(x.x); k[1] = key_of(x.y); k[2] = key_of(x.z); k[3] = key_of(x.w);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k[e] = (i + e < n) ? key_of(acc[i + e]) : KEY_SKIP;
+  }
+}
+__device__ __forceinline__ void load_chunk(const float *__restrict__ acc, int64_t c, int64_t nvec, int64_t n,
+                                           bool aligned, uint32_t k[4][4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
+    if (v < nvec) load_keys(acc, v, n, aligned, k[u]);
+    else k[u][0] = k[u][1] = k[u][2] = k[u][3] = KEY_SKIP;
+  }
+}
+
+// Grid barrier: monotonic counter, lane-0 agent release before arriving, relaxed polling with s_sleep, agent
+// acquire after (MI355X_MICROARCH.md "barrier-counter").  The spin is bounded: on a time-out `*err` is raised and
+// the caller bails out.
+__device__ __forceinline__ bool grid_barrier(uint32_t *counter, uint32_t *epoch, uint32_t *err) {
+  __shared__ uint32_t s_bad;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *epoch += 1;
+    const uint32_t target = *epoch * gridDim.x;
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0, bad = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 21) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = 1; break; }
+    }
+    if (bad) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_bad = bad;
+  }
+  __syncthreads();
+  return s_bad == 0;
+}
+
+// One level of the selection, repeated by every workgroup: wave w serves thresholds w, w+4, ...; bins are walked from
+// the top, lane l owns the l-th highest slice; a 64-lane exclusive scan finds the slice holding the wanted element.
+template <int LEVEL>
+__device__ __forceinline__ void select_level(const FullState *full, Sel *S, int64_t n, const KList &kl) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NBINS = (LEVEL == 0) ? D0_BINS : 1024;
+  constexpr int PER_LANE = NBINS / 64;
+  if (LEVEL == 0 && threadIdx.x < MAXK) {
+    uint32_t mode = MODE_NONE;
+    long long k = 0;
+    if ((int)threadIdx.x < kl.nk) {
+      k = kl.k[threadIdx.x];
+      if (k <= 0) { k = 0; mode = MODE_NONE; }
+      else if (k > n) { k = n; mode = MODE_ALL; }  // k == n runs the select: its threshold (the minimum) is real
+      else mode = MODE_GE;  // provisional: refined after the last level
+    }
+    S->k[threadIdx.x] = k;
+    S->mode[threadIdx.x] = mode;
+    S->rem[threadIdx.x] = (u64)k;
+    if (threadIdx.x == 0) S->nk = (uint32_t)kl.nk;
+  }
+  __syncthreads();
+  for (int j = wave; j < kl.nk; j += 4) {
+    if (S->mode[j] < MODE_GE) continue;
+    const u64 *hist = (LEVEL == 0) ? full->hist0 : (LEVEL == 1) ? full->hist1[S->group0_of[j]]
+                                                                 : full->hist2[S->group1_of[j]];
+    const u64 want = S->rem[j];  // 1 <= want <= population of this histogram
+    u64 mine = 0;
+    for (int i = 0; i < PER_LANE; ++i) mine += ld_agent_u64(&hist[NBINS - 1 - (lane * PER_LANE + i)]);
+    const u64 before = wave_excl_scan_u64(mine, lane);
+    if (before < want && want <= before + mine) {
+      u64 cum = before;
+      for (int i = 0; i < PER_LANE; ++i) {
+        const int bin = NBINS - 1 - (lane * PER_LANE + i);
+        const u64 c = ld_agent_u64(&hist[bin]);
+        if (want <= cum + c) { S->bin[j] = (uint32_t)bin; S->brem[j] = want - cum; S->bcnt[j] = c; break; }
+        cum += c;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // group thresholds that fell into the same bin (they share the next histogram)
+    uint32_t ng = 0, any_ordered = 0;
+    for (int i = 0; i < kl.nk; ++i) {
+      if (S->mode[i] < MODE_GE) continue;
+      S->rem[i] = S->brem[i];
+      if (LEVEL == 0) {
+        S->prefix0[i] = S->bin[i];
+        uint32_t g = 0;
+        for (; g < ng; ++g) if (S->group0_prefix[g] == S->bin[i]) break;
+        if (g == ng) S->group0_prefix[ng++] = S->bin[i];
+        S->group0_of[i] = g;
+      } else if (LEVEL == 1) {
+        const uint32_t pre = (S->prefix0[i] << 10) | S->bin[i];
+        S->prefix1[i] = pre;
+        uint32_t g = 0;
+        for (; g < ng; ++g) if (S->group1_prefix[g] == pre) break;
+        if (g == ng) S->group1_prefix[ng++] = pre;
+        S->group1_of[i] = g;
+      } else {
+        S->tau[i] = (S->prefix1[i] << 10) | S->bin[i];
+        S->ceq[i] = S->bcnt[i];
+        if (S->brem[i] != S->bcnt[i]) { S->mode[i] = MODE_ORDERED; any_ordered = 1; }
+      }
+    }
+    if (LEVEL == 0) S->ngroups0 = ng;
+    if (LEVEL == 1) S->ngroups1 = ng;
+    if (LEVEL == 2) S->any_ordered = any_ordered;
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *lds4) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
@@ -285,75 +873,10 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *lds4) {
   __syncthreads();
   return r;
 }
-
-template <bool ALIGNED>
-__global__ __launch_bounds__(SALUN_BLOCK) void k_tie_count(const float *__restrict__ acc, int64_t n,
-                                                           const TopkState *st, u64 *tie /*[nk][nchunk]*/,
-                                                           int64_t nchunk) {
-  if (st->skip || !st->any_ordered) return;
-  __shared__ uint32_t lds4[4];
-  const int nk = (int)st->nk;
-  const int64_t nvec = (n + 3) >> 2;
-  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-    uint32_t k[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
-      if (v < nvec) load_keys<ALIGNED>(acc, v, n, k[u]);
-      else k[u][0] = k[u][1] = k[u][2] = k[u][3] = KEY_SKIP;
-    }
-    for (int j = 0; j < nk; ++j) {
-      if (st->mode[j] != MODE_ORDERED) continue;
-      const uint32_t tau = st->tau[j];
-      uint32_t cnt = 0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cnt += (k[u][e] == tau);
-      const uint32_t tot = block_sum_u32(cnt, lds4);
-      if (threadIdx.x == 0) tie[(int64_t)j * nchunk + c] = tot;
-    }
-  }
-}
-
-// One workgroup per threshold: in-place exclusive scan over chunks.
-__global__ __launch_bounds__(SALUN_BLOCK) void k_tie_scan(const TopkState *st, u64 *tie, int64_t nchunk) {
-  if (st->skip || !st->any_ordered) return;
-  const int j = blockIdx.x;
-  if (st->mode[j] != MODE_ORDERED) return;
-  __shared__ u64 s_wave[4];
-  __shared__ u64 s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  u64 *row = tie + (int64_t)j * nchunk;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t base = 0; base < nchunk; base += SALUN_BLOCK) {
-    const int64_t i = base + threadIdx.x;
-    const u64 v = (i < nchunk) ? row[i] : 0;
-    const u64 ex = wave_excl_scan_u64(v, lane);
-    if (lane == 63) s_wave[wave] = ex + v;
-    __syncthreads();
-    u64 woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wave[w];
-    const u64 carry = s_carry;
-    if (i < nchunk) row[i] = carry + woff + ex;
-    __syncthreads();
-    if (threadIdx.x == SALUN_BLOCK - 1) s_carry = carry + woff + ex + v;
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------ mask write
-// Block exclusive scan of one u32 per thread (256 threads); returns the exclusive
-// prefix, *total gets the block total.
+// Block exclusive scan of one u32 per thread (256 threads); *total gets the block total.
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *lds4, uint32_t *total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
+  const uint32_t inc = wave_incl_scan_u32(v, lane);
   if (lane == 63) lds4[wave] = inc;
   __syncthreads();
   uint32_t woff = 0;
@@ -363,39 +886,161 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *ld
   return woff + inc - v;
 }
 
-template <bool ALIGNED, bool MALIGNED>
-__global__ __launch_bounds__(SALUN_BLOCK) void k_write_masks(const float *__restrict__ acc, int64_t n,
-                                                             const TopkState *st, const u64 *tie,
-                                                             int64_t nchunk, MaskPtrs out) {
-  __shared__ uint32_t s_thr[MAXK];   // key >= thr  => 1   (fast modes)
-  __shared__ uint32_t s_mode[MAXK];
-  __shared__ uint32_t s_tau[MAXK];
-  __shared__ u64 s_budget[MAXK];
+// Dynamic LDS: 2 KiB lut + nk * 1024 counters.
+__global__ __launch_bounds__(SALUN_BLOCK) void k_fullscan(const float *__restrict__ acc, int64_t n, KList kl, MaskPtrs mp,
+                                                          TopkPub *pub, FullState *full, const FastState *fs,
+                                                          u64 *tie /*[nk][nchunk]*/, int always, int aligned,
+                                                          int maligned, int values_only) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ Sel S;
   __shared__ uint32_t lds4[4];
-  if (st->skip) return;
-  const int nk = (int)st->nk;
-  if ((int)threadIdx.x < nk) {
-    const uint32_t mode = st->mode[threadIdx.x];
-    s_mode[threadIdx.x] = mode;
-    s_tau[threadIdx.x] = st->tau[threadIdx.x];
-    s_budget[threadIdx.x] = st->rem[threadIdx.x];
-    // NONE: nothing passes (real keys <= 0x7F800001); ALL: everything passes;
-    // GE: every key equal to tau is inside the budget; ORDERED: strictly greater passes here.
-    s_thr[threadIdx.x] = (mode == MODE_NONE) ? 0xFFFFFFFEu
-                         : (mode == MODE_ALL) ? 0u
-                         : (mode == MODE_GE) ? st->tau[threadIdx.x]
-                                             : st->tau[threadIdx.x] + 1u;
-  }
-  __syncthreads();
+  __shared__ uint32_t s_epoch;
+  __shared__ uint32_t s_thr[MAXK];
+  if (!always && !ld_agent_u32(&fs->fail)) return;
+  const int tid = threadIdx.x;
+  const int nk = kl.nk;
+  uint8_t *lut = reinterpret_cast<uint8_t *>(lds);  // 2048 bytes
+  uint32_t *h = lds + D0_BINS / 4;                  // up to nk * 1024 counters (pass 0 uses the first 2048)
+  if (tid == 0) s_epoch = 0;
   const int64_t nvec = (n + 3) >> 2;
+  const int64_t nchunk = (nvec + CHUNK_VEC - 1) / CHUNK_VEC;
+  // ---- phase 0: zero the global histograms
+  {
+    u64 *z = reinterpret_cast<u64 *>(full);
+    const int64_t words = (int64_t)(offsetof(FullState, bar) / 8);
+    for (int64_t i = (int64_t)blockIdx.x * SALUN_BLOCK + tid; i < words; i += (int64_t)gridDim.x * SALUN_BLOCK) z[i] = 0;
+  }
+  if (!grid_barrier(&full->bar, &s_epoch, &pub->error)) return;
+  // ---- phase 1: digit 0
+  for (int i = tid; i < D0_BINS; i += SALUN_BLOCK) h[i] = 0;
+  __syncthreads();
   for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
     uint32_t k[4][4];
+    load_chunk(acc, c, nvec, n, aligned, k);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
-      if (v < nvec) load_keys<ALIGNED>(acc, v, n, k[u]);
-      else k[u][0] = k[u][1] = k[u][2] = k[u][3] = KEY_SKIP;
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k[u][e] != KEY_SKIP) atomicAdd(&h[k[u][e] >> 20], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < D0_BINS; i += SALUN_BLOCK)
+    if (h[i]) atomicAdd(&full->hist0[i], (u64)h[i]);
+  if (!grid_barrier(&full->bar, &s_epoch, &pub->error)) return;
+  select_level<0>(full, &S, n, kl);
+  // ---- phase 2: digit 1 of keys whose digit 0 is a boundary bin
+  for (int i = tid; i < D0_BINS; i += SALUN_BLOCK) lut[i] = 0;
+  __syncthreads();
+  if (tid == 0)
+    for (uint32_t g = 0; g < S.ngroups0; ++g) lut[S.group0_prefix[g]] = (uint8_t)(g + 1);
+  for (uint32_t i = tid; i < S.ngroups0 * 1024u; i += SALUN_BLOCK) h[i] = 0;
+  __syncthreads();
+  if (S.ngroups0) {
+    for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+      uint32_t k[4][4];
+      load_chunk(acc, c, nvec, n, aligned, k);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t key = k[u][e];
+          if (key == KEY_SKIP) continue;
+          const uint32_t g0 = lut[key >> 20];
+          if (g0) atomicAdd(&h[(g0 - 1) * 1024u + ((key >> 10) & 1023u)], 1u);
+        }
     }
+    __syncthreads();
+    for (uint32_t i = tid; i < S.ngroups0 * 1024u; i += SALUN_BLOCK)
+      if (h[i]) atomicAdd(&(&full->hist1[0][0])[i], (u64)h[i]);
+  }
+  if (!grid_barrier(&full->bar, &s_epoch, &pub->error)) return;
+  select_level<1>(full, &S, n, kl);
+  // ---- phase 3: digit 2 of keys whose 21-bit prefix is a boundary prefix
+  for (uint32_t i = tid; i < S.ngroups1 * 1024u; i += SALUN_BLOCK) h[i] = 0;
+  __syncthreads();
+  if (S.ngroups1) {
+    const uint32_t ng = S.ngroups1;
+    for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+      uint32_t k[4][4];
+      load_chunk(acc, c, nvec, n, aligned, k);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t key = k[u][e];
+          if (key == KEY_SKIP || !lut[key >> 20]) continue;
+          const uint32_t pre = key >> 10;
+          for (uint32_t g = 0; g < ng; ++g)
+            if (S.group1_prefix[g] == pre) { atomicAdd(&h[g * 1024u + (key & 1023u)], 1u); break; }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ng * 1024u; i += SALUN_BLOCK)
+      if (h[i]) atomicAdd(&(&full->hist2[0][0])[i], (u64)h[i]);
+  }
+  if (!grid_barrier(&full->bar, &s_epoch, &pub->error)) return;
+  select_level<2>(full, &S, n, kl);
+  // ---- phase 4 (rare): a threshold splits a run of equal keys — per-chunk tie populations, scanned over chunks
+  if (S.any_ordered) {
+    for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+      uint32_t k[4][4];
+      load_chunk(acc, c, nvec, n, aligned, k);
+      for (int j = 0; j < nk; ++j) {
+        if (S.mode[j] != MODE_ORDERED) continue;
+        const uint32_t tau = S.tau[j];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cnt += (k[u][e] == tau);
+        const uint32_t tot = block_sum_u32(cnt, lds4);
+        if (tid == 0) tie[(int64_t)j * nchunk + c] = tot;
+      }
+    }
+    if (!grid_barrier(&full->bar, &s_epoch, &pub->error)) return;
+    for (int j = blockIdx.x; j < nk; j += gridDim.x) {  // in-place exclusive scan over chunks, one workgroup per row
+      if (S.mode[j] != MODE_ORDERED) continue;
+      __shared__ u64 s_wave[4];
+      __shared__ u64 s_carry;
+      if (tid == 0) s_carry = 0;
+      __syncthreads();
+      u64 *row = tie + (int64_t)j * nchunk;
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int64_t base = 0; base < nchunk; base += SALUN_BLOCK) {
+        const int64_t i = base + tid;
+        const u64 v = (i < nchunk) ? ld_agent_u64(&row[i]) : 0;
+        const u64 ex = wave_excl_scan_u64(v, lane);
+        if (lane == 63) s_wave[wave] = ex + v;
+        __syncthreads();
+        u64 woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_wave[w];
+        const u64 carry = s_carry;
+        if (i < nchunk) row[i] = carry + woff + ex;
+        __syncthreads();
+        if (tid == SALUN_BLOCK - 1) s_carry = carry + woff + ex + v;
+        __syncthreads();
+      }
+    }
+    if (!grid_barrier(&full->bar, &s_epoch, &pub->error)) return;
+  }
+  // ---- publish
+  if (blockIdx.x == 0 && tid < MAXK) {
+    if (tid < nk) { pub->mode[tid] = S.mode[tid]; pub->tau[tid] = S.tau[tid]; }
+    if (tid == 0) { pub->nk = (uint32_t)nk; pub->route = 2; }
+  }
+  if (values_only) return;
+  // ---- phase 5: the masks
+  if (tid < nk) {
+    const uint32_t mode = S.mode[tid];
+    // NONE: nothing passes (real keys <= 0x7F800001); ALL: everything passes;
+    // GE: every key equal to tau is inside the budget; ORDERED: strictly greater passes here.
+    s_thr[tid] = (mode == MODE_NONE) ? 0xFFFFFFFEu : (mode == MODE_ALL) ? 0u
+                 : (mode == MODE_GE) ? S.tau[tid] : S.tau[tid] + 1u;
+  }
+  __syncthreads();
+  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    uint32_t k[4][4];
+    load_chunk(acc, c, nvec, n, aligned, k);
     for (int j = 0; j < nk; ++j) {
       const uint32_t thr = s_thr[j];
       uint32_t bits[4];  // 4 mask bytes per sub-vector
@@ -403,13 +1048,12 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_write_masks(const float *__rest
       for (int u = 0; u < 4; ++u) {
         bits[u] = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          bits[u] |= (uint32_t)(k[u][e] != KEY_SKIP && k[u][e] >= thr) << (8 * e);
+        for (int e = 0; e < 4; ++e) bits[u] |= (uint32_t)(k[u][e] != KEY_SKIP && k[u][e] >= thr) << (8 * e);
       }
-      if (s_mode[j] == MODE_ORDERED) {  // workgroup-uniform branch
-        const uint32_t tau = s_tau[j];
-        u64 before = tie[(int64_t)j * nchunk + c];  // equal keys in earlier chunks
-        const u64 budget = s_budget[j];
+      if (S.mode[j] == MODE_ORDERED) {  // workgroup-uniform branch
+        const uint32_t tau = S.tau[j];
+        u64 before = ld_agent_u64(&tie[(int64_t)j * nchunk + c]);  // equal keys in earlier chunks
+        const u64 budget = S.rem[j];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // in-chunk index order: sub-vector, lane, element
           uint32_t cnt = 0;
@@ -426,13 +1070,13 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_write_masks(const float *__rest
           before += total;
         }
       }
-      uint8_t *mj = out.m[j];
+      uint8_t *mj = mp.m[j];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
+        const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + tid;
         if (v >= nvec) continue;
         const int64_t i = v << 2;
-        if (MALIGNED && i + 3 < n) {
+        if (maligned && i + 3 < n) {
           reinterpret_cast<uint32_t *>(mj)[v] = bits[u];
         } else {
 #pragma unroll
@@ -444,14 +1088,14 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_write_masks(const float *__rest
   }
 }
 
-__global__ void k_export_tau(const TopkState *st, int nk, float *out) {
+__global__ void k_export_tau(const TopkPub *pub, int nk, float *out) {
   const int j = threadIdx.x;
   if (j >= nk) return;
-  const uint32_t mode = st->mode[j];
+  const uint32_t mode = pub->mode[j];
   float v;
   if (mode == MODE_NONE) v = __uint_as_float(0x7F800000u);        // +inf: nothing selected
   else if (mode == MODE_ALL) v = -1.0f;                             // below every |x|
-  else v = st->tau[j] ? __uint_as_float(st->tau[j] - 1u) : __uint_as_float(0x7FC00000u);
+  else v = pub->tau[j] ? __uint_as_float(pub->tau[j] - 1u) : __uint_as_float(0x7FC00000u);
   out[j] = v;
 }
 
@@ -521,365 +1165,302 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_sum_partials_i64(const u64 *__r
 }
 
 // =====================================================================================================
-// Sampled single-pass path (one threshold, N >= SAMPLED_MIN_N): the three histogram passes above read the vector
-// three times before the write pass reads it a fourth time.  For SD-sized vectors (3.4 GB) that is the whole cost.
-// Here a strided sample of S = 2^20 values is ranked first (same radix select, 4 MB); its order statistics
-// 8 sigma either side of the target rank bracket the true threshold:  lo <= tau <= hi  except with
-// probability ~1e-15 for exchangeable data.  ONE pass over the vector then
-//     writes mask = [key > hi]                      (final for everything outside the bracket)
-//     counts c_gt = #{key > hi}
-//     compacts the ~0.8 % of elements with lo <= key <= hi (|value| and flat index)
-// and the exact threshold is the (k - c_gt)-th largest of the compacted values (radix select over ~N/126 elements),
-// after which those candidates' mask bytes are fixed up.  The result is the same function of the input as the
-// full-scan path (bit-exact masks).  Whenever the bracket misses (adversarial periodic data), the candidate buffer
-// overflows or the threshold splits a run of equal keys, nothing is published and the full-scan passes run as
-// before — they start with `if (st->skip) return`.
-constexpr int64_t SAMPLED_MIN_N = int64_t(1) << 25;  // measured cross-over with the full scan: ~30 M elements (tools/topk_scale.py)
-constexpr int SAMPLE_LOG2 = 20;
+//                                              host side
+// =====================================================================================================
+inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+inline int64_t chunks_of(int64_t n) { return (n + CHUNK - 1) / CHUNK; }
 
-constexpr int TIE_CAP = 4096;   // tied candidates that can be ordered by index in one workgroup
-
-struct SampCounters {
-  u64 c_gt;          // elements strictly above the bracket
-  u64 m;             // candidates kept
-  uint32_t overflow; // some workgroup ran out of its slab of the candidate buffer
-  uint32_t ok;
-  uint32_t tie_n;    // candidates equal to the threshold (ordered-tie case only)
-};
-struct SampExtra {
-  TopkState samp;    // select on the sample: threshold 0 = upper bracket, 1 = lower bracket
-  TopkState cand;    // select on the candidates
-  SampCounters cnt;
-  uint32_t tie_idx[TIE_CAP];
-};
-
-__global__ __launch_bounds__(SALUN_BLOCK) void k_sample(const float *__restrict__ acc, int64_t stride, int64_t S,
-                                                        float *__restrict__ out) {
-  // one element per stride window at a hashed offset: a fixed offset would lock onto periodic structure of the
-  // flat vector (e.g. always the centre tap of 3x3 kernels when the stride is a multiple of 9)
-  const int64_t s = (int64_t)blockIdx.x * SALUN_BLOCK + threadIdx.x;
-  if (s < S) out[s] = acc[s * stride + (int64_t)(salun_splitmix64((uint64_t)s) % (uint64_t)stride)];
-}
-
-// The one full pass.  Every workgroup appends its candidates to its own slab of the candidate buffer (LDS counter:
-// no contended global atomic); unused slab entries keep their NaN fill, which ranks after every number.
-template <bool ALIGNED, bool MALIGNED>
-__global__ __launch_bounds__(SALUN_BLOCK) void k_sampled_main(const float *__restrict__ acc, int64_t n,
-                                                              const TopkState *samp, int no_hi, int no_lo,
-                                                              uint8_t *__restrict__ mask, float *__restrict__ candv,
-                                                              uint32_t *__restrict__ candi, u64 slab_cap,
-                                                              SampCounters *cnt) {
-  __shared__ uint32_t s_count;
-  __shared__ u64 s_w[4];
-  if (threadIdx.x == 0) s_count = 0;
-  __syncthreads();
-  const uint32_t hi_key = no_hi ? 0xFFFFFFFFu : samp->tau[0];
-  const uint32_t lo_key = no_lo ? 0u : samp->tau[1];
-  const int lane = threadIdx.x & 63;
-  const int64_t nvec = (n + 3) >> 2;
-  const int64_t nchunk = (nvec + CHUNK_VEC - 1) / CHUNK_VEC;
-  float *myv = candv + (u64)blockIdx.x * slab_cap;
-  uint32_t *myi = candi + (u64)blockIdx.x * slab_cap;
-  uint32_t my_gt = 0;
-  u64 blk_gt = 0;
-  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-    uint32_t k[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
-      if (v < nvec) load_keys<ALIGNED>(acc, v, n, k[u]);
-      else k[u][0] = k[u][1] = k[u][2] = k[u][3] = KEY_SKIP;
-    }
-    uint32_t ncand = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      uint32_t bits = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t key = k[u][e];
-        const bool real = key != KEY_SKIP;
-        const bool gt = real && key > hi_key;
-        bits |= (uint32_t)gt << (8 * e);
-        my_gt += gt;
-        ncand += (real && !gt && key >= lo_key);
-      }
-      const int64_t v = c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x;
-      if (v < nvec) {
-        const int64_t i = v << 2;
-        if (MALIGNED && i + 3 < n) {
-          reinterpret_cast<uint32_t *>(mask)[v] = bits;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (i + e < n) mask[i + e] = (uint8_t)((bits >> (8 * e)) & 1u);
-        }
-      }
-    }
-    // wave-aggregated append into the workgroup's slab
-    uint32_t inc = ncand;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    const uint32_t wave_total = __shfl(inc, 63, 64);
-    if (wave_total) {
-      uint32_t base = 0;
-      if (lane == 63) base = atomicAdd(&s_count, wave_total);
-      base = __shfl(base, 63, 64);
-      u64 pos = (u64)base + (inc - ncand);
-      if (ncand) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t key = k[u][e];
-            if (key != KEY_SKIP && key <= hi_key && key >= lo_key) {
-              if (pos < slab_cap) {
-                myv[pos] = key ? __uint_as_float(key - 1u) : __uint_as_float(0x7FC00000u);  // |x| (NaN for key 0)
-                myi[pos] = (uint32_t)(((c * CHUNK_VEC + u * SALUN_BLOCK + threadIdx.x) << 2) + e);
-              }
-              ++pos;
-            }
-          }
-      }
-    }
-    if (my_gt > 0x7FFFFFFFu) { blk_gt += my_gt; my_gt = 0; }
-  }
-  blk_gt += my_gt;
-  u64 v = salun_wave_sum_u64(blk_gt);
-  if (lane == 0) s_w[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const u64 tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    if (tot) atomicAdd(&cnt->c_gt, tot);
-    const u64 mine = s_count;
-    if (mine > slab_cap) cnt->overflow = 1;
-    if (mine) atomicAdd(&cnt->m, mine < slab_cap ? mine : slab_cap);
-  }
-}
-
-__global__ void k_sampled_prep(SampExtra *ex, long long k) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const u64 m = ex->cnt.m;
-  const long long r = k - (long long)ex->cnt.c_gt;
-  const bool ok = !ex->cnt.overflow && r >= 1 && (u64)r <= m;
-  ex->cnt.ok = ok ? 1u : 0u;
-  ex->cand.kdev[0] = ok ? r : 1;
-  ex->cand.use_kdev = 1;
-}
-
-// candidates above the exact threshold -> 1; equal to it -> 1 (all ties inside the budget) or collected for ordering
-__global__ __launch_bounds__(SALUN_BLOCK) void k_sampled_fixup(const float *__restrict__ candv,
-                                                               const uint32_t *__restrict__ candi, SampExtra *ex,
-                                                               u64 cap, uint8_t *__restrict__ mask) {
-  if (!ex->cnt.ok) return;
-  const uint32_t tau = ex->cand.tau[0];
-  const uint32_t mode = ex->cand.mode[0];
-  if (tau == 0 || mode < MODE_GE) return;  // NaN threshold: slab padding is indistinguishable -> full scan
-  for (u64 i = (u64)blockIdx.x * SALUN_BLOCK + threadIdx.x; i < cap; i += (u64)gridDim.x * SALUN_BLOCK) {
-    const uint32_t key = key_of(candv[i]);
-    if (key > tau || (key == tau && mode == MODE_GE)) {
-      mask[candi[i]] = 1;
-    } else if (key == tau) {
-      const uint32_t pos = atomicAdd(&ex->cnt.tie_n, 1u);
-      if (pos < (uint32_t)TIE_CAP) ex->tie_idx[pos] = candi[i];
-    }
-  }
-}
-
-// one workgroup: order the tied candidates by flat index, admit the first `rem`, publish, switch the full scan off
-__global__ __launch_bounds__(1024) void k_sampled_finish(SampExtra *ex, TopkState *main_state, long long k,
-                                                         uint8_t *__restrict__ mask) {
-  __shared__ uint32_t s_idx[TIE_CAP];
-  if (!ex->cnt.ok) return;
-  const uint32_t tau = ex->cand.tau[0];
-  const uint32_t mode = ex->cand.mode[0];
-  if (tau == 0 || mode < MODE_GE) return;
-  if (mode == MODE_ORDERED) {
-    const uint32_t T = ex->cnt.tie_n;
-    if (T > (uint32_t)TIE_CAP || (u64)T != ex->cand.ceq[0]) return;  // too many ties for this path -> full scan
-    const u64 budget = ex->cand.rem[0];
-    for (uint32_t t = threadIdx.x; t < T; t += 1024) s_idx[t] = ex->tie_idx[t];
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < T; t += 1024) {
-      const uint32_t mine = s_idx[t];
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < T; ++j) rank += (s_idx[j] < mine);
-      if ((u64)rank < budget) mask[mine] = 1;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {  // publish for salun_mask_topk_thresholds; the full-scan kernels see skip and return
-    main_state->nk = 1;
-    main_state->k[0] = k;
-    main_state->mode[0] = MODE_GE;
-    main_state->tau[0] = tau;
-    main_state->skip = 1;
-  }
-}
-
-inline int64_t sampled_min_n() {
-  const char *e = getenv("SALUN_TOPK_SAMPLED_MIN");  // test hook: exercise the sampled path at small sizes
-  if (e && *e) return (int64_t)atoll(e);
-  return SAMPLED_MIN_N;
-}
-inline bool sampled_applies(int64_t n, int nk) {
-  return nk == 1 && n >= sampled_min_n() && n >= 65536 && n < (int64_t(1) << 32);
-}
-inline int64_t sample_size(int64_t n) {
-  int64_t S = int64_t(1) << SAMPLE_LOG2;
-  while (S > 4096 && S * 16 > n) S >>= 1;
+inline int bins_a_for(int nk) { return nk <= 2 ? 1024 : nk <= 4 ? 512 : 256; }
+inline int sample_size(int64_t n) {
+  int S = SAMPLE_MAX;
+  while (S > 1024 && (int64_t)S * 2 > n) S >>= 1;
   return S;
 }
-inline u64 cand_capacity(int64_t n) { return (u64)(((n / 64 + 4095) / 4096) * 4096 + 4096); }
-inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+inline int main_grid_for(int64_t n) {
+  const int64_t nfull = n / CHUNK;
+  return (int)(nfull < MAIN_GRID ? (nfull < 1 ? 1 : nfull) : MAIN_GRID);
+}
+// worst-case (p = 1/2) share of the values inside one bracket, for sizing: 2 * margin / S plus the bin-edge slack
+inline double bracket_fraction(int64_t S) {
+  const double margin = std::ceil(BRACKET_SIGMAS * 0.5 * std::sqrt((double)S)) + 8.0;
+  return 2.0 * margin / (double)S + 0.002;
+}
 
-inline size_t state_bytes() { return (sizeof(TopkState) + 255) & ~size_t(255); }
+// Sizes of one fast-route instance over `n` elements with `nk` thresholds whose brackets hold a fraction `f` each.
+struct FastLayout {
+  int grid;          // k_main workgroups
+  int ga;            // k_hist_a workgroups (1024 threads, one wave per slab row)
+  int gr;            // k_resolve workgroups per threshold = short-list segments per threshold
+  uint32_t cap;      // slab entries per (workgroup, threshold)
+  size_t off_fs, off_keys, off_cnt, off_gt, off_slabs, off_list2, off_seg, bytes;
+};
+inline FastLayout fast_layout(int64_t n, int nk, double f) {
+  FastLayout L;
+  L.grid = main_grid_for(n);
+  const double per_slab = f * (double)n / (double)L.grid;
+  L.cap = (uint32_t)(1.5 * per_slab) + 256u;
+  const int rows = L.grid * nk;
+  // LDS atomics per workgroup vs the depth of the flush's atomic chains (one global atomic per bin per workgroup)
+  const double cands = f * (double)n * (double)nk;
+  int ga = (int)(cands / 8192.0);
+  if (ga < 32) ga = 32;
+  if (ga > 256) ga = 256;
+  if (ga < nk) ga = nk;  // workgroups 0..nk-1 also reduce the c_gt rows
+  L.ga = ga;
+  // k_resolve workgroups per threshold (= short-list segments per threshold): one wave per slab row, more when the
+  // rows are long (large n)
+  int gpj = (L.grid + 15) / 16;
+  if (per_slab > 1024.0) gpj *= 4;
+  if (gpj > 256 / nk) gpj = 256 / nk;
+  if (gpj < 1) gpj = 1;
+  L.gr = gpj;
+  size_t b = 0;
+  L.off_fs = b;    b += align256(sizeof(FastState));
+  L.off_keys = b;  b += align256(sizeof(uint32_t) * (size_t)SAMPLE_MAX);
+  L.off_cnt = b;   b += align256(sizeof(uint32_t) * (size_t)rows);
+  L.off_gt = b;    b += align256(sizeof(uint32_t) * (size_t)rows);
+  L.off_slabs = b; b += align256(sizeof(uint2) * (size_t)rows * (size_t)L.cap);
+  L.off_list2 = b; b += align256(sizeof(uint2) * (size_t)nk * (size_t)L.gr * (size_t)STAGE_CAP);
+  L.off_seg = b;   b += align256(sizeof(uint32_t) * (size_t)nk * (size_t)L.gr);
+  L.bytes = b;
+  return L;
+}
 
-// the three histogram + selection rounds over `data` (state zeroed by the caller): fills state->tau / mode / rem
-inline int run_select(const float *data, int64_t n, const KList &kl, TopkState *state, hipStream_t st) {
-  const bool aligned = salun_aligned16(data);
-  const int grid = salun_grid_for(n, CHUNK);
-  // Histogram kernels end with one global atomic per non-empty bin per workgroup, all workgroups hitting the
-  // same few hundred addresses: keep that chain short (2 workgroups per CU) — the read side still has
-  // 8 waves x 4 KiB in flight per CU.
-  const int hgrid = grid < HIST_MAX_GRID ? grid : HIST_MAX_GRID;
-  // dynamic LDS of the pass-1/2 histogram kernels: 2 KiB lut + one 4 KiB histogram per threshold
-  const size_t lds_bytes = D0_BINS + sizeof(uint32_t) * (size_t)kl.nk * 1024;
-  if (aligned) hipLaunchKernelGGL(k_hist0<true>, dim3(hgrid), dim3(SALUN_BLOCK), 0, st, data, n, state);
-  else hipLaunchKernelGGL(k_hist0<false>, dim3(hgrid), dim3(SALUN_BLOCK), 0, st, data, n, state);
+inline bool fast_applies(int64_t n) { return n >= FAST_MIN_N && n < (int64_t(1) << 32); }
+inline bool two_level_applies(int64_t n, int nk) { return n >= TWO_LEVEL_MIN_N && 2 * nk <= MAXK; }
+
+// Workspace: [TopkPub | FullState | tie rows | outer fast instance | (two-level) sample + inner pub/full + inner fast instance]
+struct WsLayout {
+  size_t off_pub, off_full, off_tie, off_fast, off_sample, off_ipub, off_ifull, off_ifast, bytes;
+  FastLayout outer, inner;
+  bool fast, two_level;
+};
+inline WsLayout ws_layout(int64_t n, int nk) {
+  WsLayout W;
+  size_t b = 0;
+  W.off_pub = b;  b += align256(sizeof(TopkPub));
+  W.off_full = b; b += align256(sizeof(FullState));
+  W.off_tie = b;  b += align256(sizeof(u64) * (size_t)nk * (size_t)(chunks_of(n) + 1));
+  W.fast = fast_applies(n);
+  W.two_level = W.fast && two_level_applies(n, nk);
+  W.off_fast = W.off_sample = W.off_ipub = W.off_ifull = W.off_ifast = b;
+  if (W.fast) {
+    const int64_t S2 = int64_t(1) << SAMPLE2_LOG2;
+    W.outer = fast_layout(n, nk, W.two_level ? bracket_fraction(S2) : bracket_fraction(sample_size(n)));
+    W.off_fast = b; b += W.outer.bytes;
+    if (W.two_level) {
+      W.off_sample = b; b += align256(sizeof(float) * (size_t)S2);
+      W.off_ipub = b;   b += align256(sizeof(TopkPub));
+      W.off_ifull = b;  b += align256(sizeof(FullState));
+      W.inner = fast_layout(S2, 2 * nk, bracket_fraction(sample_size(S2)));
+      W.off_ifast = b;  b += W.inner.bytes;
+    }
+  }
+  W.bytes = b;
+  return W;
+}
+
+int g_cu_count = 0;
+inline int fullscan_grid(int64_t n) {
+  if (g_cu_count == 0) {
+    // 2 KiB + 16 x 4 KiB of dynamic LDS at the maximum threshold count: above the 64 KiB default
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fullscan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              96 * 1024);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      g_cu_count = cus;
+    else
+      g_cu_count = 64;
+  }
+  int64_t g = 2 * (int64_t)g_cu_count;  // resident with room to spare: the grid barrier needs every workgroup running
+  if (g > 512) g = 512;
+  const int64_t nc = chunks_of(n);
+  if (g > nc) g = nc < 1 ? 1 : nc;
+  return (int)g;
+}
+
+template <bool VO>
+inline void launch_main(int nk, int grid, hipStream_t st, const float *acc, int64_t n, FastState *fs, const MaskPtrs &mp,
+                        uint2 *slabs, uint32_t *slab_cnt, uint32_t *wg_gt, uint32_t cap, int bins_a) {
+#define SALUN_MAIN(NKT)                                                                                             \
+  hipLaunchKernelGGL((k_main<NKT, VO>), dim3(grid), dim3(SALUN_BLOCK), 0, st, acc, n, fs, mp, slabs, slab_cnt, wg_gt, \
+                     cap, nk, bins_a)
+  if (nk <= 1) SALUN_MAIN(1);
+  else if (nk <= 2) SALUN_MAIN(2);
+  else if (nk <= 3) SALUN_MAIN(3);
+  else if (nk <= 4) SALUN_MAIN(4);
+  else if (nk <= 6) SALUN_MAIN(6);
+  else if (nk <= 8) SALUN_MAIN(8);
+  else if (nk <= 10) SALUN_MAIN(10);
+  else if (nk <= 12) SALUN_MAIN(12);
+  else SALUN_MAIN(16);
+#undef SALUN_MAIN
+}
+
+// k_main .. k_finish + the fallback launch of one fast instance whose FastState already holds the brackets.
+inline int run_fast_tail(const float *acc, int64_t n, const KList &kl, const MaskPtrs &mp, bool values_only, char *fast_base,
+                         const FastLayout &L, TopkPub *pub, FullState *full, u64 *tie, bool aligned, bool maligned,
+                         hipStream_t st) {
+  const int nk = kl.nk;
+  FastState *fs = reinterpret_cast<FastState *>(fast_base + L.off_fs);
+  uint32_t *slab_cnt = reinterpret_cast<uint32_t *>(fast_base + L.off_cnt);
+  uint32_t *wg_gt = reinterpret_cast<uint32_t *>(fast_base + L.off_gt);
+  uint2 *slabs = reinterpret_cast<uint2 *>(fast_base + L.off_slabs);
+  uint2 *list2 = reinterpret_cast<uint2 *>(fast_base + L.off_list2);
+  uint32_t *seg_cnt = reinterpret_cast<uint32_t *>(fast_base + L.off_seg);
+  const int bins_a = bins_a_for(nk);
+  if (values_only) launch_main<true>(nk, L.grid, st, acc, n, fs, mp, slabs, slab_cnt, wg_gt, L.cap, bins_a);
+  else launch_main<false>(nk, L.grid, st, acc, n, fs, mp, slabs, slab_cnt, wg_gt, L.cap, bins_a);
   SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_select<0>, dim3(1), dim3(1024), 0, st, state, n, kl);
+  hipLaunchKernelGGL(k_hist_a, dim3(L.ga), dim3(1024), sizeof(uint32_t) * (size_t)nk * bins_a, st, fs, slabs, slab_cnt,
+                     wg_gt, L.cap, L.grid, nk, bins_a);
   SALUN_LAUNCH_CHECK();
-  if (aligned) hipLaunchKernelGGL((k_hist12<1, true>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, data, n, state);
-  else hipLaunchKernelGGL((k_hist12<1, false>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, data, n, state);
+  if (values_only)
+    hipLaunchKernelGGL(k_resolve<true>, dim3(L.gr * nk), dim3(1024), 0, st, fs, slabs, slab_cnt, L.cap, L.grid, nk, bins_a,
+                       L.gr, list2, seg_cnt, mp);
+  else
+    hipLaunchKernelGGL(k_resolve<false>, dim3(L.gr * nk), dim3(1024), 0, st, fs, slabs, slab_cnt, L.cap, L.grid, nk,
+                       bins_a, L.gr, list2, seg_cnt, mp);
   SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_select<1>, dim3(1), dim3(1024), 0, st, state, n, kl);
+  if (values_only) hipLaunchKernelGGL(k_finish<true>, dim3(nk), dim3(1024), 0, st, fs, pub, list2, seg_cnt, L.gr, mp);
+  else hipLaunchKernelGGL(k_finish<false>, dim3(nk), dim3(1024), 0, st, fs, pub, list2, seg_cnt, L.gr, mp);
   SALUN_LAUNCH_CHECK();
-  if (aligned) hipLaunchKernelGGL((k_hist12<2, true>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, data, n, state);
-  else hipLaunchKernelGGL((k_hist12<2, false>), dim3(hgrid), dim3(SALUN_BLOCK), lds_bytes, st, data, n, state);
-  SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_select<2>, dim3(1), dim3(1024), 0, st, state, n, kl);
+  const size_t lds_bytes = D0_BINS + sizeof(uint32_t) * (size_t)(nk < 2 ? 2 : nk) * 1024;
+  hipLaunchKernelGGL(k_fullscan, dim3(fullscan_grid(n)), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, kl, mp, pub, full, fs,
+                     tie, 0, (int)aligned, (int)maligned, (int)values_only);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }
-inline int64_t chunks_of(int64_t n) { return (n + CHUNK - 1) / CHUNK; }
 
 }  // namespace
 
 // ================================================================== C-ABI =======
 SALUN_EXPORT size_t salun_mask_topk_workspace_bytes(int64_t n, int nk) {
   if (n < 0 || nk < 1 || nk > MAXK) return 0;
-  size_t b = align256(state_bytes() + sizeof(u64) * (size_t)nk * (size_t)(chunks_of(n) + 1));
-  if (sampled_applies(n, nk))
-    b += align256(sizeof(SampExtra)) + align256(sizeof(float) * (size_t)sample_size(n)) +
-         2 * align256(sizeof(float) * (size_t)cand_capacity(n));
-  return b;
+  return ws_layout(n, nk).bytes;
 }
 
-SALUN_EXPORT int salun_mask_topk(const float *acc, int64_t n, const int64_t *ks, int nk,
-                                 uint8_t *const *masks_out, void *ws, size_t ws_bytes,
-                                 salun_stream_t stream) {
-  if (n < 0 || nk < 1 || nk > MAXK || !ks || !masks_out || !ws || (n > 0 && !acc)) return SALUN_EINVAL;
-  for (int j = 0; j < nk; ++j)
-    if (n > 0 && !masks_out[j]) return SALUN_EINVAL;
-  if (ws_bytes < salun_mask_topk_workspace_bytes(n, nk)) return SALUN_ENOSPC;
-  if (n == 0) return SALUN_OK;
+SALUN_EXPORT int salun_mask_topk_ex(const float *acc, int64_t n, const int64_t *ks, int nk, uint8_t *const *masks_out,
+                                    void *ws, size_t ws_bytes, unsigned flags, salun_stream_t stream) {
+  const bool values_only = (flags & SALUN_TOPK_VALUES_ONLY) != 0;
+  if (n < 0 || nk < 1 || nk > MAXK || !ks || !ws || (n > 0 && !acc)) return SALUN_EINVAL;
+  if (!values_only) {
+    if (!masks_out) return SALUN_EINVAL;
+    for (int j = 0; j < nk; ++j)
+      if (n > 0 && !masks_out[j]) return SALUN_EINVAL;
+  }
+  const WsLayout W = ws_layout(n, nk);
+  if (ws_bytes < W.bytes) return SALUN_ENOSPC;
   hipStream_t st = salun_hip_stream(stream);
-  TopkState *state = static_cast<TopkState *>(ws);
-  u64 *tie = reinterpret_cast<u64 *>(static_cast<char *>(ws) + state_bytes());
-  const int64_t nchunk = chunks_of(n);
+  char *base = static_cast<char *>(ws);
+  TopkPub *pub = reinterpret_cast<TopkPub *>(base + W.off_pub);
+  FullState *full = reinterpret_cast<FullState *>(base + W.off_full);
+  u64 *tie = reinterpret_cast<u64 *>(base + W.off_tie);
   KList kl;
   MaskPtrs mp;
   kl.nk = nk;
   bool maligned = true;
   for (int j = 0; j < MAXK; ++j) {
     kl.k[j] = (j < nk) ? (long long)ks[j] : 0;
-    mp.m[j] = (j < nk) ? masks_out[j] : nullptr;
-    if (j < nk && !salun_aligned4(masks_out[j])) maligned = false;
+    mp.m[j] = (j < nk && !values_only) ? masks_out[j] : nullptr;
+    if (j < nk && !values_only && !salun_aligned4(masks_out[j])) maligned = false;
+  }
+  if (n == 0) {  // nothing to rank: publish "nothing selected"
+    if (hipMemsetAsync(pub, 0, sizeof(TopkPub), st) != hipSuccess) return SALUN_EIO;
+    return SALUN_OK;
   }
   const bool aligned = salun_aligned16(acc);
-  if (hipMemsetAsync(state, 0, sizeof(TopkState), st) != hipSuccess) return SALUN_EIO;
-  const int grid = salun_grid_for(n, CHUNK);
-
-  if (sampled_applies(n, nk) && ks[0] > 0 && ks[0] < n) {
-    // ---- sampled single-pass attempt (see the comment above k_sample); publishes and sets state->skip on success
-    char *base = static_cast<char *>(ws) + align256(state_bytes() + sizeof(u64) * (size_t)nk * (size_t)(nchunk + 1));
-    SampExtra *ex = reinterpret_cast<SampExtra *>(base);
-    const int64_t S = sample_size(n);
-    const u64 cap = cand_capacity(n);
-    float *samp = reinterpret_cast<float *>(base + align256(sizeof(SampExtra)));
-    float *candv = reinterpret_cast<float *>(reinterpret_cast<char *>(samp) + align256(sizeof(float) * (size_t)S));
-    uint32_t *candi = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(candv) + align256(sizeof(float) * cap));
-    if (hipMemsetAsync(ex, 0, sizeof(SampExtra), st) != hipSuccess) return SALUN_EIO;
-    if (hipMemsetAsync(candv, 0xFF, sizeof(float) * cap, st) != hipSuccess) return SALUN_EIO;  // NaN: ranks last
-    const double pfrac = (double)ks[0] / (double)n;
-    const double sigma = std::sqrt((double)S * pfrac * (1.0 - pfrac));
-    const int64_t margin = (int64_t)std::ceil(8.0 * sigma) + 64;
-    const int64_t ks_s = (int64_t)std::llround(pfrac * (double)S);
-    const int no_hi = ks_s - margin < 1, no_lo = ks_s + margin > S;
+  const bool fast = W.fast && aligned && maligned && !(flags & SALUN_TOPK_FORCE_FULL_SCAN);
+  if (!fast) {
+    // full scan directly: one memset (publication block + barrier word) and the persistent kernel
+    if (hipMemsetAsync(pub, 0, sizeof(TopkPub), st) != hipSuccess) return SALUN_EIO;
+    if (hipMemsetAsync(&full->bar, 0, 8, st) != hipSuccess) return SALUN_EIO;
+    const size_t lds_bytes = D0_BINS + sizeof(uint32_t) * (size_t)(nk < 2 ? 2 : nk) * 1024;
+    hipLaunchKernelGGL(k_fullscan, dim3(fullscan_grid(n)), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, kl, mp, pub, full,
+                       static_cast<const FastState *>(nullptr), tie, 1, (int)aligned, (int)maligned, (int)values_only);
+    SALUN_LAUNCH_CHECK();
+    return SALUN_OK;
+  }
+  const int bins_a = bins_a_for(nk);
+  char *fast_base = base + W.off_fast;
+  FastState *fs = reinterpret_cast<FastState *>(fast_base + W.outer.off_fs);
+  const bool two_level = W.two_level;
+  if (!two_level) {
+    const int S = sample_size(n);
+    uint32_t *skeys = reinterpret_cast<uint32_t *>(fast_base + W.outer.off_keys);
+    hipLaunchKernelGGL(k_sample, dim3(S / 1024), dim3(1024), 0, st, acc, n, S, skeys);
+    SALUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bracket, dim3(1), dim3(1024), 0, st, skeys, n, kl, S, bins_a, fs, pub, full);
+    SALUN_LAUNCH_CHECK();
+  } else {
+    // ---- brackets = exact order statistics of a 2^20-element sample (this same route on the sample, values only)
+    const int64_t S2 = int64_t(1) << SAMPLE2_LOG2;
+    float *samp = reinterpret_cast<float *>(base + W.off_sample);
+    TopkPub *ipub = reinterpret_cast<TopkPub *>(base + W.off_ipub);
+    FullState *ifull = reinterpret_cast<FullState *>(base + W.off_ifull);
+    char *ifast = base + W.off_ifast;
+    FastState *ifs = reinterpret_cast<FastState *>(ifast + W.inner.off_fs);
     KList k2;
-    k2.nk = 2;
-    for (int j = 0; j < MAXK; ++j) k2.k[j] = 0;
-    k2.k[0] = no_hi ? 1 : ks_s - margin;   // descending rank of the upper bracket in the sample
-    k2.k[1] = no_lo ? S : ks_s + margin;   // ... and of the lower bracket
-    hipLaunchKernelGGL(k_sample, dim3((unsigned)((S + SALUN_BLOCK - 1) / SALUN_BLOCK)), dim3(SALUN_BLOCK), 0, st, acc,
-                       n / S, S, samp);
+    RankList rl;
+    k2.nk = 2 * nk;
+    for (int j = 0; j < MAXK; ++j) { k2.k[j] = 0; rl.hi[j] = rl.lo[j] = 0; }
+    for (int j = 0; j < nk; ++j) {
+      long long k = ks[j] > n ? n : ks[j];
+      if (k <= 0) { k2.k[2 * j] = k2.k[2 * j + 1] = 0; continue; }
+      const double p = (double)k / (double)n;
+      const double sigma = std::sqrt((double)S2 * p * (1.0 - p));
+      const long long margin = (long long)std::ceil(BRACKET_SIGMAS * sigma) + 8;
+      const long long rho = std::llround(p * (double)S2);
+      long long rhi = rho - margin, rlo = rho + margin;
+      if (rhi < 1) rhi = 0;
+      if (rlo > S2) rlo = 0;
+      rl.hi[j] = rhi; rl.lo[j] = rlo;
+      k2.k[2 * j] = rhi ? rhi : 1;       // unbounded sides are not read back
+      k2.k[2 * j + 1] = rlo ? rlo : 1;
+    }
+    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)(S2 / SALUN_BLOCK)), dim3(SALUN_BLOCK), 0, st, acc, n / S2, S2, samp);
     SALUN_LAUNCH_CHECK();
-    int rc = run_select(samp, S, k2, &ex->samp, st);
+    const int S1 = sample_size(S2);
+    uint32_t *ikeys = reinterpret_cast<uint32_t *>(ifast + W.inner.off_keys);
+    hipLaunchKernelGGL(k_sample, dim3(S1 / 1024), dim3(1024), 0, st, samp, S2, S1, ikeys);
+    SALUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bracket, dim3(1), dim3(1024), 0, st, ikeys, S2, k2, S1, bins_a_for(2 * nk), ifs, ipub, ifull);
+    SALUN_LAUNCH_CHECK();
+    MaskPtrs none;
+    for (int j = 0; j < MAXK; ++j) none.m[j] = nullptr;
+    u64 *itie = tie;  // the sample has fewer chunks than the vector: the outer rows are large enough and not yet in use
+    if ((size_t)(2 * nk) * (size_t)(chunks_of(S2) + 1) > (size_t)nk * (size_t)(chunks_of(n) + 1)) return SALUN_EINVAL;
+    int rc = run_fast_tail(samp, S2, k2, none, true, ifast, W.inner, ipub, ifull, itie, true, true, st);
     if (rc != SALUN_OK) return rc;
-    const int mgrid = grid < 2048 ? grid : 2048;
-    const u64 slab_cap = cap / (u64)mgrid;
-#define SALUN_SMAIN(A, M)                                                                                          \
-  hipLaunchKernelGGL((k_sampled_main<A, M>), dim3(mgrid), dim3(SALUN_BLOCK), 0, st, acc, n, &ex->samp, no_hi, no_lo, \
-                     mp.m[0], candv, candi, slab_cap, &ex->cnt)
-    if (aligned && maligned) SALUN_SMAIN(true, true);
-    else if (aligned) SALUN_SMAIN(true, false);
-    else if (maligned) SALUN_SMAIN(false, true);
-    else SALUN_SMAIN(false, false);
-#undef SALUN_SMAIN
-    SALUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sampled_prep, dim3(1), dim3(64), 0, st, ex, (long long)ks[0]);
-    SALUN_LAUNCH_CHECK();
-    KList k1;
-    k1.nk = 1;
-    for (int j = 0; j < MAXK; ++j) k1.k[j] = 0;
-    k1.k[0] = 1;  // replaced on the device by cand.kdev[0]
-    rc = run_select(candv, (int64_t)cap, k1, &ex->cand, st);
-    if (rc != SALUN_OK) return rc;
-    hipLaunchKernelGGL(k_sampled_fixup, dim3(1024), dim3(SALUN_BLOCK), 0, st, candv, candi, ex, cap, mp.m[0]);
-    SALUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sampled_finish, dim3(1), dim3(1024), 0, st, ex, state, (long long)ks[0], mp.m[0]);
+    hipLaunchKernelGGL(k_bracket_from_inner, dim3(1), dim3(1024), 0, st, ipub, n, kl, rl, bins_a, fs, pub, full);
     SALUN_LAUNCH_CHECK();
   }
+  return run_fast_tail(acc, n, kl, mp, values_only, fast_base, W.outer, pub, full, tie, aligned, maligned, st);
+}
 
-  {
-    const int rc = run_select(acc, n, kl, state, st);  // returns at once on the device if the sampled path published
-    if (rc != SALUN_OK) return rc;
-  }
-  // rare path, early-exits on the device when no threshold splits a run of ties
-  if (aligned) hipLaunchKernelGGL(k_tie_count<true>, dim3(grid), dim3(SALUN_BLOCK), 0, st, acc, n, state, tie, nchunk);
-  else hipLaunchKernelGGL(k_tie_count<false>, dim3(grid), dim3(SALUN_BLOCK), 0, st, acc, n, state, tie, nchunk);
-  SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_tie_scan, dim3(nk), dim3(SALUN_BLOCK), 0, st, state, tie, nchunk);
-  SALUN_LAUNCH_CHECK();
-#define SALUN_WRITE(A, M) \
-  hipLaunchKernelGGL((k_write_masks<A, M>), dim3(grid), dim3(SALUN_BLOCK), 0, st, acc, n, state, tie, nchunk, mp)
-  if (aligned && maligned) SALUN_WRITE(true, true);
-  else if (aligned) SALUN_WRITE(true, false);
-  else if (maligned) SALUN_WRITE(false, true);
-  else SALUN_WRITE(false, false);
-#undef SALUN_WRITE
-  SALUN_LAUNCH_CHECK();
-  return SALUN_OK;
+SALUN_EXPORT int salun_mask_topk(const float *acc, int64_t n, const int64_t *ks, int nk,
+                                 uint8_t *const *masks_out, void *ws, size_t ws_bytes,
+                                 salun_stream_t stream) {
+  return salun_mask_topk_ex(acc, n, ks, nk, masks_out, ws, ws_bytes, 0u, stream);
 }
 
 SALUN_EXPORT int salun_mask_topk_thresholds(const void *ws, int nk, float *tau_out, salun_stream_t stream) {
   if (!ws || !tau_out || nk < 1 || nk > MAXK) return SALUN_EINVAL;
   hipLaunchKernelGGL(k_export_tau, dim3(1), dim3(64), 0, salun_hip_stream(stream),
-                     static_cast<const TopkState *>(ws), nk, tau_out);
+                     static_cast<const TopkPub *>(ws), nk, tau_out);
   SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+SALUN_EXPORT int salun_mask_topk_status(const void *ws, int *route_out, int *error_out, salun_stream_t stream) {
+  if (!ws || !route_out || !error_out) return SALUN_EINVAL;
+  TopkPub host;
+  hipStream_t st = salun_hip_stream(stream);
+  if (hipMemcpyAsync(&host, ws, sizeof(TopkPub), hipMemcpyDeviceToHost, st) != hipSuccess) return SALUN_EIO;
+  if (hipStreamSynchronize(st) != hipSuccess) return SALUN_EIO;
+  *route_out = (int)host.route;
+  *error_out = (int)host.error;
   return SALUN_OK;
 }
 

@@ -53,6 +53,47 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
     return rk, lrk, ws
 
 
+def counted_ranks(device: Optional[torch.device] = None) -> int:
+    """Number of ranks that took part in an actual all-reduce (SUM of ones) — what `rccl_ranks` in the bench line
+    reports; 1 when single-process."""
+    if not is_dist():
+        return 1
+    if device is None:
+        device = (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl"
+                  else torch.device("cpu"))
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(float(one.item())))
+
+
+def launch_ranks(script: str, argv: list, nproc: int, require_devices: bool = True, extra_env: Optional[dict] = None
+                 ) -> int:
+    """`python script --gpus N` without torchrun: re-exec the script as N ranks of ONE node through
+    `torch.distributed.run` (rendezvous on 127.0.0.1, free port), one rank per GPU.  Fails loudly when the node has
+    fewer than N devices (`require_devices=False` is the CPU/gloo self-test of this launcher).  Returns the exit
+    code of the launched job; the caller exits with it."""
+    import socket
+    import subprocess
+    import sys
+    if nproc < 2:
+        raise ValueError("launch_ranks is for N > 1")
+    if require_devices:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < nproc:
+            raise SystemExit(f"{os.path.basename(script)} --gpus {nproc} needs {nproc} devices on this node, "
+                             f"found {have}: refusing to run fewer ranks than asked")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // nproc)))
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     if world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -83,6 +124,26 @@ def shard_bounds(n: int, rk: Optional[int] = None, ws: Optional[int] = None) -> 
     ws = world_size() if ws is None else ws
     per = (n + ws - 1) // ws
     return min(rk * per, n), min((rk + 1) * per, n)
+
+
+def balanced_slice(b: int, rk: Optional[int] = None, ws: Optional[int] = None) -> tuple[int, int]:
+    """Shard [lo, hi) of a global batch of b samples: sizes differ by at most one and no shard is empty while
+    b >= world_size (ceil-sized shards leave the last ranks short or empty on a ragged tail batch)."""
+    rk = rank() if rk is None else rk
+    ws = world_size() if ws is None else ws
+    return rk * b // ws, (rk + 1) * b // ws
+
+
+def shard_loss_scale(loader) -> float:
+    """Factor that turns this rank's shard-mean loss into its share of the GLOBAL batch mean under the AVG
+    all-reduce of the gradients:  mean_global = (1/ws) * sum_r (n_r * ws / b) * mean_r.  1.0 when single-process or
+    when the loader does not shard."""
+    ws = world_size()
+    sh = getattr(loader, "last_shard", None)
+    if ws <= 1 or sh is None:
+        return 1.0
+    lo, hi, b = sh
+    return (hi - lo) * ws / float(b)
 
 
 class BucketedGradReducer:

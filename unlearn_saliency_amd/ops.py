@@ -39,9 +39,11 @@ def _dev(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, allow_none: b
 _ws: dict[tuple, torch.Tensor] = {}
 
 
-def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+def workspace(nbytes: int, device: torch.device, tag: str = "") -> torch.Tensor:
+    """`tag` separates buffers whose contents must survive other ops' scratch use (the top-k publication block is
+    read back by mask_topk_thresholds after arbitrary calls in between)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream, tag)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -61,28 +63,45 @@ def saliency_accumulate(acc: torch.Tensor, g: torch.Tensor, scale: float = 1.0,
 
 
 # ----------------------------------------------------------------------------- K2
-def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch.Tensor]] = None
-              ) -> list[torch.Tensor]:
-    """One u8 0/1 mask per k: the k largest |acc| (ties: lowest flat index first)."""
+def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch.Tensor]] = None,
+              flags: int = 0) -> list[torch.Tensor]:
+    """One u8 0/1 mask per k: the k largest |acc| (ties: lowest flat index first).
+    `flags`: _lib.SALUN_TOPK_* (FORCE_FULL_SCAN for A/B tests, VALUES_ONLY publishes the thresholds without
+    writing masks — returns [])."""
     L = _lib.lib()
     n, nk = acc.numel(), len(ks)
     if not 1 <= nk <= _lib.SALUN_MAX_THRESHOLDS:
         raise ValueError(f"1 <= len(ks) <= {_lib.SALUN_MAX_THRESHOLDS}")
-    if out is None:
-        out = [torch.empty(n, dtype=torch.uint8, device=acc.device) for _ in ks]
-    assert len(out) == nk and all(o.numel() == n for o in out)
+    values_only = bool(flags & _lib.SALUN_TOPK_VALUES_ONLY)
+    if values_only:
+        out, marr = [], None
+    else:
+        if out is None:
+            out = [torch.empty(n, dtype=torch.uint8, device=acc.device) for _ in ks]
+        assert len(out) == nk and all(o.numel() == n for o in out)
+        marr = (c_void_p * nk)(*[_dev(o, torch.uint8, "mask").value for o in out])
     nbytes = L.salun_mask_topk_workspace_bytes(c_int64(n), c_int(nk))
-    ws = workspace(nbytes, acc.device)
+    ws = workspace(nbytes, acc.device, "topk")
     karr = (c_int64 * nk)(*[int(k) for k in ks])
-    marr = (c_void_p * nk)(*[_dev(o, torch.uint8, "mask").value for o in out])
-    check(L.salun_mask_topk(_dev(acc, torch.float32, "acc"), c_int64(n), karr, c_int(nk), marr,
-                            c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()), "salun_mask_topk")
+    check(L.salun_mask_topk_ex(_dev(acc, torch.float32, "acc"), c_int64(n), karr, c_int(nk), marr,
+                               c_void_p(ws.data_ptr()), c_size_t(ws.numel()), ctypes.c_uint(flags), _stream()),
+          "salun_mask_topk")
     return list(out)
+
+
+def mask_topk_status(device: torch.device) -> tuple[int, int]:
+    """(route, error) of the LAST mask_topk call on this device: route 1 = single-read, 2 = full scan; error 1 = a grid
+    barrier of the full scan timed out.  Synchronises the stream (diagnostics / tests only)."""
+    ws = workspace(0, device, "topk")
+    route, err = c_int(0), c_int(0)
+    check(_lib.lib().salun_mask_topk_status(c_void_p(ws.data_ptr()), ctypes.byref(route), ctypes.byref(err), _stream()),
+          "salun_mask_topk_status")
+    return route.value, err.value
 
 
 def mask_topk_thresholds(device: torch.device, nk: int) -> torch.Tensor:
     """|acc| value of the k-th element for the thresholds of the LAST mask_topk call on this device."""
-    ws = workspace(0, device)
+    ws = workspace(0, device, "topk")
     out = torch.empty(nk, dtype=torch.float32, device=device)
     check(_lib.lib().salun_mask_topk_thresholds(c_void_p(ws.data_ptr()), c_int(nk), c_void_p(out.data_ptr()),
                                                 _stream()), "salun_mask_topk_thresholds")

@@ -27,6 +27,72 @@ class _FlatOptimizer(torch.optim.Optimizer):
             from .dist import BucketedGradReducer
             self._reducer = BucketedGradReducer(arena, self.overlap_buckets)
 
+    def close(self) -> None:
+        """Detach from the arena: removes the gradient-bucket hooks this optimizer registered on the parameters (a
+        second optimizer on the same model would otherwise leave the old reducer firing extra all-reduces on every
+        backward).  Called by the epoch driver when the optimizer is done; idempotent."""
+        if self._reducer is not None:
+            self._reducer.remove()
+            self._reducer = None
+        self._closed = True
+
+    def __del__(self):
+        try:
+            if getattr(self, "_reducer", None) is not None:
+                self._reducer.remove()
+        except Exception:
+            pass
+
+    # ---- torch.optim-layout state (checkpoints in the reference's [model, optimizer, step] format resume)
+    _STATE_VECTORS: tuple = ()
+
+    def state_dict(self):
+        """Same layout as the torch.optim optimizer this one replaces: `state[i]` holds per-parameter tensors (views
+        of the flat state vectors, cloned) so a checkpoint written here loads into torch.optim.SGD / Adam and back."""
+        sd = super().state_dict()
+        state = {}
+        started = self.steps > 0
+        if started:
+            for i, (o, k, shp) in enumerate(zip(self.arena.offsets, self.arena.numels, self.arena.shapes)):
+                ent = {}
+                for key, attr in self._STATE_VECTORS:
+                    vec = getattr(self, attr, None)
+                    if vec is not None:
+                        ent[key] = vec[o:o + k].view(shp).clone()
+                if self._STEP_KEY:
+                    ent["step"] = torch.tensor(float(self.steps))
+                state[i] = ent
+        sd["state"] = state
+        sd["salun_steps"] = self.steps
+        return sd
+
+    _STEP_KEY = False
+
+    def load_state_dict(self, sd):
+        state = sd.get("state", {})
+        groups = sd.get("param_groups")
+        if groups:
+            for g, src in zip(self.param_groups, groups):
+                for key, val in src.items():
+                    if key != "params":
+                        g[key] = val
+        steps = int(sd.get("salun_steps", 0))
+        for i, (o, k, shp) in enumerate(zip(self.arena.offsets, self.arena.numels, self.arena.shapes)):
+            ent = state.get(i, state.get(str(i)))
+            if not ent:
+                continue
+            for key, attr in self._STATE_VECTORS:
+                vec = getattr(self, attr, None)
+                if vec is not None and key in ent:
+                    vec[o:o + k].copy_(ent[key].reshape(-1).to(vec.device, vec.dtype))
+            if "step" in ent:
+                steps = max(steps, int(float(ent["step"])))
+        self.steps = steps
+        self._after_load()
+
+    def _after_load(self) -> None:
+        pass
+
     def set_mask(self, mask_u8: Optional[torch.Tensor]) -> None:
         """Flat u8 0/1 vector (FlatArena.pack_mask) or None for an unmasked update."""
         if mask_u8 is not None:
@@ -56,10 +122,15 @@ class FusedMaskedSGD(_FlatOptimizer):
     (Classification/unlearn/impl.py:68-73) + `_apply_mask_to_grads` + `_restore_masked_params`
     (Classification/unlearn/RL.py:11-34) in one `salun_masked_sgd_step` launch."""
 
+    _STATE_VECTORS = (("momentum_buffer", "momentum_buffer"),)
+
     def __init__(self, arena: FlatArena, lr: float, momentum: float = 0.0, weight_decay: float = 0.0):
         super().__init__(arena, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.momentum_buffer = arena.new_like() if momentum != 0 else None
         self._first_step = True
+
+    def _after_load(self) -> None:
+        self._first_step = self.steps == 0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -78,6 +149,9 @@ class FusedMaskedAdam(_FlatOptimizer):
     (DDPM/runners/diffusion.py:582-593, DDPM/functions/__init__.py:9-18) as two launches:
     `salun_grad_sqnorm` (deterministic reduction, result stays on the device) and
     `salun_masked_adam_step` (reads the norm from device memory: no host sync anywhere)."""
+
+    _STATE_VECTORS = (("exp_avg", "exp_avg"), ("exp_avg_sq", "exp_avg_sq"))
+    _STEP_KEY = True
 
     def __init__(self, arena: FlatArena, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, amsgrad: bool = False, grad_clip: Optional[float] = None):

@@ -30,6 +30,24 @@ from . import gradsink, ops
 OVERLAP_WGRAD = os.environ.get("SALUN_WGRAD_OVERLAP", "1") != "0"
 
 
+class overlap_disabled:
+    """Context manager: keep backward-weight on the main stream.  Needed whenever something else than the
+    convolution kernels writes a parameter's `.grad` during the same backward pass — e.g. the l1 penalty of FT_l1 /
+    GA_l1 (`_steps.l1_regularization`), whose AccumulateGrad `w.grad.add_()` runs on the main stream and would race
+    with a side-stream `salun_conv2d_backward_weight` accumulating into the same slice."""
+
+    def __enter__(self):
+        global OVERLAP_WGRAD
+        self._prev = OVERLAP_WGRAD
+        OVERLAP_WGRAD = False
+        return self
+
+    def __exit__(self, *exc):
+        global OVERLAP_WGRAD
+        OVERLAP_WGRAD = self._prev
+        return False
+
+
 def reset_join_state() -> None:
     """Forget a pending end-of-backward join (only needed after a backward pass was aborted by an exception) and make
     the current streams wait for whatever the side streams still have in flight."""

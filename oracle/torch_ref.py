@@ -121,3 +121,93 @@ def masked_adam_step_cpu(model, optimizer, mask, grad_clip=1.0):
             if param.grad is not None:
                 param.grad *= mask[name].to(param.grad.device)
     optimizer.step()
+
+
+# ------------------------------------------------------------------ SD pieces (plain torch, any device / dtype)
+class PlainLDM:
+    """The slice of the reference's LatentDiffusion the SalUn scripts call, in plain torch ops around a given U-Net:
+    q_sample (SD/ldm/models/diffusion/ddpm.py:424-430), apply_model (:1121), shared_step -> p_losses with
+    logvar = 0, l_simple_weight = 1, original_elbo_weight = 0 (:1093-1109, :1286-1319).  Schedule: the LDM "linear"
+    schedule linspace(sqrt(start), sqrt(end))**2 in float64 (ldm/modules/diffusionmodules/util.py:24-30)."""
+
+    def __init__(self, unet, timesteps=1000, linear_start=0.00085, linear_end=0.0120):
+        import numpy as np
+        self.unet, self.num_timesteps = unet, int(timesteps)
+        betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=np.float64) ** 2
+        ac = np.cumprod(1.0 - betas, axis=0)
+        p = next(unet.parameters())
+        self.device = p.device
+        self.sqrt_ac = torch.tensor(np.sqrt(ac), dtype=torch.float32, device=p.device)
+        self.sqrt_1mac = torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32, device=p.device)
+
+    def q_sample(self, x_start, t, noise):
+        a = self.sqrt_ac.index_select(0, t).view(-1, 1, 1, 1)
+        b = self.sqrt_1mac.index_select(0, t).view(-1, 1, 1, 1)
+        return a * x_start + b * noise
+
+    def apply_model(self, x_noisy, t, cond):
+        return self.unet(x_noisy, t, context=cond)
+
+    def shared_step(self, z, c):
+        t = torch.randint(0, self.num_timesteps, (z.shape[0],), device=self.device).long()
+        noise = torch.randn_like(z)
+        return nn.MSELoss()(self.apply_model(self.q_sample(z, t, noise), t, c), noise)
+
+
+def sd_saliency_gradients(ldm: PlainLDM, batches, c_guidance) -> Dict[str, torch.Tensor]:
+    """SD/train-scripts/generate_mask.py:130-174 (generate_nsfw_mask; :24-69 for generate_mask): per batch
+    loss = -MSE(noise, (1+g) eps(z_t, c) - g eps(z_t, null)), uniform t, per-tensor `gradients[name] += grad`.
+    (The reference draws an unused `t` first, :141-143; not reproduced: it only advances the generator.)"""
+    unet = ldm.unet
+    unet.eval()
+    gradients = {name: 0 for name, _ in unet.named_parameters()}
+    for z, c_forget, c_null in batches:
+        unet.zero_grad()
+        t = torch.randint(0, ldm.num_timesteps, (z.shape[0],), device=ldm.device).long()
+        noise = torch.randn_like(z)
+        z_noisy = ldm.q_sample(z, t, noise)
+        preds = (1 + c_guidance) * ldm.apply_model(z_noisy, t, c_forget) - c_guidance * ldm.apply_model(z_noisy, t, c_null)
+        loss = -nn.MSELoss()(noise, preds)
+        loss.backward()
+        with torch.no_grad():
+            for name, param in unet.named_parameters():
+                if param.grad is not None:
+                    gradients[name] = gradients[name] + param.grad.detach().clone()
+    return gradients
+
+
+def sd_unlearn(ldm: PlainLDM, forget_batches, remain_batches, alpha, lr, mask, train_method="full", epochs=1):
+    """SD/train-scripts/nsfw_removal.py:60-150 (random_label.py:58-139 is the same body): remain loss via shared_step,
+    forget/pseudo outputs on one noisy latent, loss = MSE(forget_out, pseudo_out.detach()) + alpha * remain_loss,
+    per-tensor `p.grad *= mask[name]`, torch.optim.Adam(lr).  Returns (losses, optimizer)."""
+    unet = ldm.unet
+    params = [p for n, p in unet.named_parameters() if train_method == "full" or "attn2" in n]
+    unet.train()
+    opt = torch.optim.Adam(params, lr=lr)
+    losses = []
+    for _ in range(epochs):
+        remain_iter = iter(remain_batches)
+        for z_f, c_forget, c_pseudo in forget_batches:
+            opt.zero_grad()
+            unet.zero_grad()
+            try:
+                z_r, c_r = next(remain_iter)
+            except StopIteration:
+                remain_iter = iter(remain_batches)
+                z_r, c_r = next(remain_iter)
+            remain_loss = ldm.shared_step(z_r, c_r)
+            t = torch.randint(0, ldm.num_timesteps, (z_f.shape[0],), device=ldm.device).long()
+            noise = torch.randn_like(z_f)
+            z_noisy = ldm.q_sample(z_f, t, noise)
+            forget_out = ldm.apply_model(z_noisy, t, c_forget)
+            pseudo_out = ldm.apply_model(z_noisy, t, c_pseudo).detach()
+            loss = nn.MSELoss()(forget_out, pseudo_out) + alpha * remain_loss
+            loss.backward()
+            losses.append(float(loss.item()))
+            if mask:
+                for n, p in unet.named_parameters():
+                    if p.grad is not None:
+                        p.grad *= mask[n].to(p.grad.device)
+            opt.step()
+    unet.eval()
+    return losses, opt

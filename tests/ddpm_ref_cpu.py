@@ -138,6 +138,7 @@ def cpu_unlearn(cfg, model, method, alpha, remain_batches, forget_batches, mask_
             for p, k in zip(params, sizes):
                 p.copy_(torch.from_numpy(flat[off:off + k]).view_as(p))
                 off += k
+    cpu_unlearn.last_moments = (m1, v)  # Adam's exp_avg / exp_avg_sq after the run (flat, arena order)
     return losses
 
 

@@ -125,9 +125,24 @@ def make_ddpm():
     # ---- runner-level captures ------------------------------------------------------------
     def run_reference(method_name, args_kw, cfg, remain, forget, mask=None, cwd=None):
         """Run Diffusion.<method_name>() with data loaders replaced and every random draw recorded."""
-        rec = dict(randn=[], randint=[], keep=[])
+        rec = dict(randn=[], randint=[], keep=[], loss=[], eps_mse=[])
         real_randn_like, real_randint, real_pml = torch.randn_like, torch.randint, RM.prob_mask_like
+        real_backward = torch.Tensor.backward
+        real_registry = dict(RD.loss_registry_conditional)
         cap = {}
+
+        def backward(self, *a, **k):  # `loss.backward()` of the loop body: the step's total loss
+            if self.dim() == 0:
+                rec["loss"].append(float(self.item()))
+            return real_backward(self, *a, **k)
+
+        def recording(fn):
+            def wrapped(*a, **k):
+                v = fn(*a, **k)
+                if v.dim() == 0:
+                    rec["eps_mse"].append(float(v.item()))  # every eps-MSE evaluation, in call order
+                return v
+            return wrapped
 
         def randn_like(x, **k):
             r = real_randn_like(x, **k)
@@ -150,7 +165,8 @@ def make_ddpm():
         def get_opt(config, params):
             params = list(params)
             cap["params"] = params
-            return real_get_opt(config, params)
+            cap["opt"] = real_get_opt(config, params)
+            return cap["opt"]
 
         with tempfile.TemporaryDirectory() as d:
             os.makedirs(os.path.join(d, "ckpts"))
@@ -166,6 +182,9 @@ def make_ddpm():
             RD.get_forget_dataset = lambda a, c_, l: (Loader(remain), Loader(forget))
             RD.get_optimizer = get_opt
             torch.randn_like, torch.randint, RM.prob_mask_like = randn_like, randint, pml
+            torch.Tensor.backward = backward
+            for key in list(RD.loss_registry_conditional):
+                RD.loss_registry_conditional[key] = recording(real_registry[key])
             old = os.getcwd()
             os.chdir(cwd or d)
             try:
@@ -179,6 +198,8 @@ def make_ddpm():
             finally:
                 os.chdir(old)
                 torch.randn_like, torch.randint, RM.prob_mask_like = real_randn_like, real_randint, real_pml
+                torch.Tensor.backward = real_backward
+                RD.loss_registry_conditional.update(real_registry)
                 RD.get_optimizer = real_get_opt
         return rec, cap, files
 
@@ -212,10 +233,19 @@ def make_ddpm():
                                     forget, mask=files["mask"])
         holder = SimpleNamespace(parameters=lambda: cap["params"])
         s = summarize(holder)
+        # Adam moments after the run (linear / quadratic in the clipped, masked gradients: the quantities to compare
+        # at fp32 round-off, unlike the weights, whose first Adam steps move by ~lr * sign(g)) and the loss scalars
+        st = cap["opt"].state
+        m1 = np.concatenate([st[p]["exp_avg"].reshape(-1).numpy() for p in cap["params"]])
+        m2 = np.concatenate([st[p]["exp_avg_sq"].reshape(-1).numpy() for p in cap["params"]])
         np.savez_compressed(os.path.join(HERE, f"ddpm_unlearn_{method}.npz"), param_sample=s["sample"],
                             tensor_sums=s["tensor_sums"], randn=np.stack(tensors(rec["randn"])),
                             randint=np.stack(tensors(rec["randint"])),
-                            keep=np.stack(tensors(rec["keep"])) if rec["keep"] else np.zeros(0))
+                            keep=np.stack(tensors(rec["keep"])) if rec["keep"] else np.zeros(0),
+                            step_loss=np.array(rec["loss"], np.float64), eps_mse=np.array(rec["eps_mse"], np.float64),
+                            exp_avg_sample=m1[::SAMPLE_STRIDE], exp_avg_sq_sample=m2[::SAMPLE_STRIDE],
+                            exp_avg_norm=np.float64(np.linalg.norm(m1.astype(np.float64))),
+                            exp_avg_sq_sum=np.float64(m2.astype(np.float64).sum()))
 
     # (f) Fisher information: T = 4, n_chunks = 2, two samples
     cfgf = ddpm_small_config(T=4)

@@ -69,6 +69,50 @@ def main():
     np.savez(os.path.join(HERE, "boundary_expanding.npz"), init_seed=9,
              **{"sd_" + k: v.numpy() for k, v in model.state_dict().items()})
 
+    # ---- F1 GA / GA_l1 / FT / FT_l1 (Classification/unlearn/GA.py:44-206, FT.py:44-180): 2 epochs on the tiny BN
+    # network; GA walks 2 forget batches, FT walks 3 retain batches.  The returned value of the epoch function (train
+    # top-1) is captured through the print the reference makes of it.
+    #   GA_l1 is declared WITHOUT the `mask` parameter (GA.py:156) while the epoch driver always passes one
+    #   (impl.py:108-110): through the registry it raises TypeError in the reference.  Its golden is produced by
+    #   driving the undecorated epoch function with the driver's own optimizer / scheduler construction.
+    def run_plain(name, loaders, args, maskd):
+        model = TinyCNN()
+        model.load_state_dict(tiny_state(21))
+        getattr(ref_unlearn, name)(loaders, model, crit, args, maskd)
+        return model
+
+    fb = tiny_batches(2, 16, 700)
+    rb = tiny_batches(3, 16, 800)
+    mk = lambda bs: MG._ListLoader([(torch.from_numpy(x), torch.from_numpy(y)) for x, y in bs])
+    for name, key, batches in (("GA", "forget", fb), ("FT", "retain", rb), ("FT_l1", "retain", rb)):
+        for tag, use_mask in (("masked", True), ("unmasked", False)):
+            mflat, maskd = _mask_for(TinyCNN(), 900)
+            model = run_plain(name, {key: mk(batches)}, _args(unlearn=name, alpha=2e-3, no_l1_epochs=0),
+                              maskd if use_mask else None)
+            np.savez(os.path.join(HERE, f"{name.lower()}_{tag}.npz"), alpha=2e-3, no_l1_epochs=0,
+                     mask=mflat.astype(np.uint8) if use_mask else np.zeros(0, np.uint8),
+                     **{"sd_" + k: v.numpy() for k, v in model.state_dict().items()})
+    # GA_l1: the undecorated function + the driver's optimizer (impl.py:68-73, 96-99)
+    raised = None
+    try:
+        run_plain("GA_l1", {"forget": mk(fb)}, _args(unlearn="GA_l1", alpha=2e-3), None)
+    except TypeError as e:
+        raised = str(e)
+    assert raised and "positional argument" in raised, raised
+    inner = ref_unlearn.GA_l1.__closure__[0].cell_contents
+    model = TinyCNN()
+    model.load_state_dict(tiny_state(21))
+    a = _args(unlearn="GA_l1", alpha=2e-3)
+    opt = torch.optim.SGD(model.parameters(), a.unlearn_lr, momentum=a.momentum, weight_decay=a.weight_decay)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[91, 136], gamma=0.1)
+    accs = []
+    for epoch in range(a.unlearn_epochs):
+        accs.append(float(inner({"forget": mk(fb)}, model, crit, opt, epoch, a)))
+        sched.step()
+    np.savez(os.path.join(HERE, "ga_l1_unmasked.npz"), alpha=2e-3, reference_registry_error=raised,
+             train_acc=np.array(accs), mask=np.zeros(0, np.uint8),
+             **{"sd_" + k: v.numpy() for k, v in model.state_dict().items()})
+
     # ---- F2 RL_proximal: 24 forget + 40 retain uint8 samples, merged + shuffled by the reference's DataLoader
     fds, rds = next_rows_datasets()
     forget = torch.utils.data.DataLoader(fds, batch_size=16, shuffle=False)

@@ -54,3 +54,52 @@ def test_entry_points_parse_and_refuse_to_run_without_a_gpu(tmp_path, module, ar
                        env=dict(os.environ, PYTHONPATH=root), timeout=300)
     assert r.returncode != 0
     assert "ROCm device" in (r.stderr + r.stdout), (r.stderr[-800:], r.stdout[-400:])
+
+
+# ----------------------------------------------------------------------------------------- SD command lines
+def _sd_script(name):
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "unlearn_saliency_amd", "SD", "train-scripts")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    spec = importlib.util.spec_from_file_location("sd_cli_" + name, os.path.join(d, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("name", ["generate_mask", "random_label", "nsfw_removal", "proximal_gradient"])
+def test_sd_flags_and_defaults_match_reference(golden_dir, name):
+    """Every flag of the reference's SD/train-scripts parser (tests/golden/cli.json, read from its add_argument calls)
+    exists with the same default and required-ness; the only deliberate deviations are documented in the script:
+    nsfw_removal's `--lr` parses as float (the reference declares type=int, which rejects 1e-5)."""
+    ref = json.load(open(os.path.join(golden_dir, "cli.json")))["sd"][name]
+    parser = _sd_script(name).build_parser()
+    actions = {a.dest: a for a in parser._actions if a.dest != "help"}
+    for flag, spec in ref.items():
+        assert flag in actions, f"reference flag --{flag} missing from {name}.py"
+        a = actions[flag]
+        assert a.required == spec.get("required", False), flag
+        if "default" in spec and not a.required:
+            assert a.default == spec["default"], (flag, a.default, spec["default"])
+        want = {"str": str, "int": int, "float": float, "bool": bool}.get(spec.get("type"))
+        if (name, flag) == ("nsfw_removal", "lr"):
+            assert a.type is float and spec["type"] == "int"
+        elif want is not None:
+            assert a.type is want, (flag, a.type, want)
+    assert set(actions) - set(ref) == {"latents", "synthetic", "bf16"}
+
+
+def test_sd_entry_points_refuse_without_a_gpu(tmp_path):
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the entry points would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "unlearn_saliency_amd", "SD", "train-scripts", "nsfw_removal.py")
+    r = subprocess.run([sys.executable, script, "--train_method", "full", "--synthetic", "1", "--device", "0"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "ROCm device" in (r.stderr + r.stdout), r.stderr[-600:]

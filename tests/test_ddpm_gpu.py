@@ -139,11 +139,34 @@ def test_saliency_unlearn_matches_reference(golden_dir, workdir, method):
         model = runner.saliency_unlearn()
     after = flat_params(model)
     assert np.array_equal(after[mask == 0].view(np.uint32), before[mask == 0].view(np.uint32))
+    # (1) the loop's loss scalar at every step — forget term + alpha * eps-MSE of the reference run — to 1e-5 relative
+    #     (north_star's bar for the eps-MSE), U-Net forward on the MFMA convolution / fused GroupNorm kernels
+    losses = np.array([float(v) for v in runner.step_losses], np.float64)
+    rel = np.abs(losses - g["step_loss"]) / np.abs(g["step_loss"])
+    print(f"{method}: step losses {losses}, reference {g['step_loss']}, rel. deviation {rel}")
+    assert rel.max() <= 1e-5, rel
+    # (2) Adam's moments after the run: exp_avg is linear and exp_avg_sq quadratic in the clipped, masked gradients,
+    #     so they carry the gradients' fp32 round-off unamplified — unlike the weights, whose first Adam steps move by
+    #     ~lr * sign(g) (a gradient that is 1e-6 away from zero flips a whole lr).  Bar: 1e-5 of the vector's scale
+    #     + 1e-3 relative per element (fp32 summation order of the convolutions / GroupNorm differs from the library's)
+    opt = runner.last_optimizer
+    m1, v = opt.exp_avg.cpu().numpy(), opt.exp_avg_sq.cpu().numpy()
+    s1, s2 = np.abs(g["exp_avg_sample"]).max(), np.abs(g["exp_avg_sq_sample"]).max()
+    d1 = np.abs(m1[::STRIDE] - g["exp_avg_sample"]) / s1
+    d2 = np.abs(v[::STRIDE] - g["exp_avg_sq_sample"]) / s2
+    print(f"{method}: exp_avg max dev {d1.max():.2e} of scale, exp_avg_sq max dev {d2.max():.2e} of scale")
+    assert np.allclose(m1[::STRIDE], g["exp_avg_sample"], rtol=1e-3, atol=1e-5 * s1), d1.max()
+    assert np.allclose(v[::STRIDE], g["exp_avg_sq_sample"], rtol=2e-3, atol=1e-5 * s2), d2.max()
+    assert abs(np.linalg.norm(m1.astype(np.float64)) - float(g["exp_avg_norm"])) <= 1e-5 * float(g["exp_avg_norm"])
+    assert abs(v.astype(np.float64).sum() - float(g["exp_avg_sq_sum"])) <= 2e-5 * float(g["exp_avg_sq_sum"])
+    assert not m1[mask == 0].any() and not v[mask == 0].any()
+    # (3) the weights: every update is bounded by Adam's step size (|dp| <= ~lr per step) and all but the
+    #     near-zero-gradient elements agree to a small fraction of lr; per-tensor sums to 1e-4
     lr = cfg.optim.lr
     got, ref = after[::STRIDE], g["param_sample"]
     close = np.abs(got - ref) <= 0.02 * lr + 1e-6 * np.abs(ref)
     assert close.mean() > 0.99, close.mean()
-    assert np.abs(got - ref).max() <= 5 * lr
+    assert np.abs(got - ref).max() <= 2 * 2 * lr   # two steps, at most +-lr each on both sides
     sums = np.array([float(p.detach().double().sum()) for p in model.parameters()])
     assert np.allclose(sums, g["tensor_sums"], rtol=1e-4, atol=3e-3)
 

@@ -114,7 +114,18 @@ def test_saliency_unlearn_restatement_vs_reference(oracle_mod, golden_dir, metho
     model = fill_params(Conditional_Model(cfg), 7000)
     before = flat_params(model)
     with R.replay(randn=g["randn"], randint=g["randint"], keep=g["keep"]):
-        R.cpu_unlearn(cfg, model, method, 1e-3, _batches(300), _batches(400, label=0), mask, n_iters=2)
+        losses = R.cpu_unlearn(cfg, model, method, 1e-3, _batches(300), _batches(400, label=0), mask, n_iters=2)
+    # the loop's loss scalar at every step (forget term + alpha * eps-MSE): 1e-5 relative (north_star)
+    assert np.allclose(losses, g["step_loss"], rtol=1e-5, atol=0), (losses, g["step_loss"])
+    # Adam's moments are linear / quadratic in the clipped, masked gradients: the per-weight quantities that can be
+    # compared at fp32 round-off (the weights themselves move by ~lr * sign(g) in the first steps)
+    m1, v = R.cpu_unlearn.last_moments
+    s1, s2 = np.abs(g["exp_avg_sample"]).max(), np.abs(g["exp_avg_sq_sample"]).max()
+    assert np.allclose(m1[::STRIDE], g["exp_avg_sample"], rtol=1e-4, atol=1e-5 * s1)
+    assert np.allclose(v[::STRIDE], g["exp_avg_sq_sample"], rtol=2e-4, atol=1e-5 * s2)
+    assert abs(np.linalg.norm(m1.astype(np.float64)) - float(g["exp_avg_norm"])) <= 1e-5 * float(g["exp_avg_norm"])
+    assert abs(v.astype(np.float64).sum() - float(g["exp_avg_sq_sum"])) <= 2e-5 * float(g["exp_avg_sq_sum"])
+    assert not m1[mask == 0].any() and not v[mask == 0].any()
     after = flat_params(model)
     # masked-out weights are bit-identical to the start (Adam state stays 0 there)
     assert np.array_equal(after[mask == 0].view(np.uint32), before[mask == 0].view(np.uint32))

@@ -171,3 +171,43 @@ def test_rl_proximal_plugin_matches_reference(golden_dir):
     _check_state(model, g, rtol=1e-4, atol=2e-6)
     with pytest.raises(AttributeError):
         unlearn.get_unlearn_method("RL_proximal")(loaders, model, nn.CrossEntropyLoss(), _args(), None)
+
+
+# ------------------------------------------------------------------------------------ GA / GA_l1 / FT / FT_l1 plugins
+@pytest.mark.parametrize("name,tag", [("GA", "masked"), ("GA", "unmasked"), ("FT", "masked"), ("FT", "unmasked"),
+                                      ("FT_l1", "masked"), ("FT_l1", "unmasked"), ("GA_l1", "unmasked")])
+def test_ga_ft_plugins_match_reference(golden_dir, name, tag):
+    """Registry plugins on the device (fused masked-SGD step, l1 term through autograd on the main stream) against the
+    state_dict produced by the reference's own GA / FT / FT_l1 / GA_l1 functions (tests/golden/make_golden_next.py)."""
+    from unlearn_saliency_amd.Classification import unlearn
+    g = np.load(os.path.join(golden_dir, f"{name.lower()}_{tag}.npz"))
+    model = TinyCNN()
+    init = tiny_state(21)
+    model.load_state_dict(init)
+    model.cuda()
+    mask = None
+    if g["mask"].size:
+        sizes = [p.numel() for p in model.parameters()]
+        off = np.cumsum([0] + sizes)
+        mask = {n: torch.from_numpy(g["mask"][off[i]:off[i + 1]].astype(np.int64)).view_as(p)
+                for i, (n, p) in enumerate(model.named_parameters())}
+    key, batches = ("forget", tiny_batches(2, 16, 700)) if name.startswith("GA") else ("retain", tiny_batches(3, 16, 800))
+    args = _args(unlearn=name, alpha=float(g["alpha"]), no_l1_epochs=int(g["no_l1_epochs"]) if "no_l1_epochs" in g else 0)
+    unlearn.get_unlearn_method(name)({key: _loader(batches)}, model, nn.CrossEntropyLoss(), args, mask)
+    _check_state(model, g, rtol=1e-4, atol=2e-6)
+    if mask is not None:
+        names = [n for n, _ in model.named_parameters()]
+        sd = model.state_dict()
+        now = np.concatenate([sd[n].reshape(-1).cpu().numpy() for n in names])
+        was = np.concatenate([init[n].reshape(-1).numpy() for n in names])
+        frozen = g["mask"] == 0
+        assert np.array_equal(now[frozen].view(np.uint32), was[frozen].view(np.uint32))
+
+
+def test_validate_and_mia_on_the_device_match_the_reference(golden_dir):
+    """A7 on the GPU: `trainer.validate` (top-1, sample-weighted) and `SVC_MIA` on device-resident loaders against the
+    numbers the reference's own functions returned for the same model and data (eval_tinycnn.npz)."""
+    import importlib
+    cpu_test = importlib.import_module("test_eval_vs_golden")
+    assert hasattr(cpu_test, "run_eval"), "tests/test_eval_vs_golden.py exposes run_eval(device)"
+    cpu_test.run_eval(golden_dir, "cuda")

@@ -156,3 +156,39 @@ def test_rl_proximal_vs_reference(oracle_mod, golden_dir):
     assert len(taus) == len(g["thresholds"])
     assert np.allclose(np.array(taus, np.float32), g["thresholds"], rtol=1e-4, atol=1e-9)
     _check_state(model, g, rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ F1 GA / GA_l1 / FT / FT_l1
+def _l1(model):
+    return torch.linalg.norm(torch.cat([p.view(-1) for p in model.parameters()]), ord=1)
+
+
+@pytest.mark.parametrize("name,tag", [("ga", "masked"), ("ga", "unmasked"), ("ft", "masked"), ("ft", "unmasked"),
+                                      ("ft_l1", "masked"), ("ft_l1", "unmasked"), ("ga_l1", "unmasked")])
+def test_ga_ft_family_vs_reference(oracle_mod, golden_dir, name, tag):
+    """Oracle replay of Classification/unlearn/GA.py:44-206 and FT.py:44-180 (2 epochs): loss sign, the l1 term
+    (constant alpha for GA_l1, alpha * (1 - epoch / (epochs - no_l1_epochs)) for FT_l1), mask multiply + SGD + restore
+    as the oracle's fused step — against the state_dict the reference's own functions produced."""
+    g = np.load(os.path.join(golden_dir, f"{name}_{tag}.npz"))
+    model = TinyCNN()
+    model.load_state_dict(tiny_state(21))
+    fl = _Flat(model)
+    crit = nn.CrossEntropyLoss()
+    mask = g["mask"] if g["mask"].size else None
+    batches = tiny_batches(2, 16, 700) if name.startswith("ga") else tiny_batches(3, 16, 800)
+    epochs, alpha = 2, float(g["alpha"])
+    model.train()
+    for epoch in range(epochs):
+        for x, y in batches:
+            x, y = torch.from_numpy(x), torch.from_numpy(y)
+            loss = crit(model(x), y)
+            if name.startswith("ga"):
+                loss = -loss
+            if name == "ga_l1":
+                loss = loss + alpha * _l1(model)
+            if name == "ft_l1":
+                loss = loss + alpha * (1 - epoch / (epochs - int(g["no_l1_epochs"]))) * _l1(model)
+            fl.step(oracle_mod, loss, mask)
+    _check_state(model, g, rtol=1e-5, atol=2e-7)
+    if name == "ga_l1":
+        assert "positional argument" in str(g["reference_registry_error"])  # the reference's own registry call fails

@@ -11,13 +11,59 @@ from types import SimpleNamespace
 ND = 38_632_323
 
 
-def main():
+def cpu_baseline(cfg, steps=1):
+    """The reference's saliency_unlearn loop body (DDPM/runners/diffusion.py:520-593, method rl) as plain PyTorch-CPU
+    ops on this host's cores: remain eps-MSE + forget/pseudo MSE, backward, clip_grad_norm_, per-tensor mask multiply,
+    torch.optim.Adam — `steps` steps at batch 128 after one warm-up step at batch 16 (bounded sample)."""
+    from oracle import torch_ref
+    from unlearn_saliency_amd.DDPM.models.diffusion import Conditional_Model
+    from unlearn_saliency_amd.DDPM.runners.diffusion import get_beta_schedule
+    torch.manual_seed(0)
+    model = Conditional_Model(cfg)
+    model.train()
+    d = cfg.diffusion
+    betas = torch.from_numpy(get_beta_schedule(d.beta_schedule, beta_start=d.beta_start, beta_end=d.beta_end,
+                                               num_diffusion_timesteps=d.num_diffusion_timesteps)).float()
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.optim.lr)
+    mask = {n: (torch.rand_like(p) < 0.5).to(torch.int64) for n, p in model.named_parameters()}
+
+    def step(bs):
+        x, c = torch.rand(bs, 3, 32, 32) * 2 - 1, torch.randint(1, 10, (bs,))
+        xf, cf = torch.rand(bs, 3, 32, 32) * 2 - 1, torch.zeros(bs, dtype=torch.int64)
+        T = betas.numel()
+        t = torch.randint(0, T, (bs,))
+        e = torch.randn_like(x)
+        out = model(torch_ref.qsample_cpu(x, e, betas, t), t.float(), c, cond_drop_prob=0.1, mode="train")
+        remain = torch_ref.eps_mse_cpu(e, out)
+        e = torch.randn_like(xf)
+        xt = torch_ref.qsample_cpu(xf, e, betas, t)
+        o = model(xt, t.float(), cf, mode="train")
+        with torch.no_grad():
+            pseudo = model(xt, t.float(), (cf + 1) % 10, mode="train")
+        loss = torch.nn.MSELoss()(pseudo, o) + 1e-3 * remain
+        opt.zero_grad()
+        loss.backward()
+        torch_ref.masked_adam_step_cpu(model, opt, mask, 1.0)
+
+    step(16)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(128)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} rl step(s) at batch 128 (CFG-DDPM 38.6 M params fp32: remain pass + forget pass + pseudo "
+                      f"pass, clip, 334x mask-mul, torch.optim.Adam) after one warm-up step at batch 16",
+            "ms_per_step": 1e3 * dt / steps, "host_cpu_count": os.cpu_count()}
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mask_batches", type=int, default=40)
     ap.add_argument("--library_conv", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args(argv)
     from unlearn_saliency_amd.DDPM.functions import load_config, get_optimizer, cycle
     from unlearn_saliency_amd.DDPM.runners.diffusion import Diffusion
     from unlearn_saliency_amd.flat import arena_of
@@ -71,9 +117,16 @@ def main():
     tail_s = 1e-3 * sum(s.elapsed_time(e) for s, e in ev) / a.steps
     alg = 33 * ND  # grad sq-norm (4 B) + masked Adam (29 B) per element, SURVEY.md §8 D2
     flops_step = 128 * (2 * 37.34 + 12.45) * 1e9
+    from unlearn_saliency_amd import conv as sconv
     out = {"metric": "ddpm_unlearn_steps_per_sec (CFG-DDPM/CIFAR-10 class-forget, rl, batch 128)",
-           "value": a.steps / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt / a.steps, "steps": a.steps,
+           "value": a.steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic", "params": ND,
+           "config": {"workload": "CFG-DDPM U-Net (38,632,323 params) / CIFAR-10-shaped synthetic set, class-0 forget, "
+                                  "saliency_unlearn method rl, alpha 1e-3, batch 128, Adam 1e-4, clip 1.0, SalUn mask "
+                                  "ratio 0.5 (BASELINE.json configs[3] at 1 GPU)",
+                      "per_gpu_batch": 128, "parallelism": "dp1",
+                      "library_conv_calls": dict(sconv.LIBRARY_CONV_CALLS, total=sconv.library_conv_calls())},
            "mask_gen": {"batches": a.mask_batches, "saliency_sec": t1 - t0, "topk_sec": t2 - t1},
            "roofline": {"kernel": "salun_grad_sqnorm + salun_masked_adam_step", "bound": "hbm",
                         "achieved": alg / tail_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / tail_s / 1e9 / 8000.0,
@@ -81,6 +134,10 @@ def main():
            "fwd_bwd": {"bound": "mfma", "tflop_per_step": flops_step / 1e12,
                        "achieved_whole_step": flops_step / (dt / a.steps) / 1e12, "peak": 157.3, "unit": "TFLOP/s"},
            "mfma_convs": not a.library_conv}
+    out["roofline"]["traffic"] = None
+    if not a.no_cpu_baseline:
+        with contextlib.redirect_stdout(sys.stderr):
+            out["cpu_baseline"] = cpu_baseline(cfg)
     print(json.dumps(out), flush=True)
 
 

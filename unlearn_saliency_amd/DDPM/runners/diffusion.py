@@ -255,21 +255,62 @@ class Diffusion(object):
         optimizer = get_optimizer(config, arena=arena)
         if mask:
             optimizer.set_mask(arena.pack_mask(strip_prefix(mask)))
-        if config.model.ema:
-            raise NotImplementedError("EMA is off in cifar10_saliency_unlearn.yml (out of scope, SURVEY.md §2 D6)")
+        ema_helper = self._ema(model)  # reference :509-513 (off in cifar10_saliency_unlearn.yml)
         model.train()
         start = time.time()
+        self.last_optimizer = optimizer
+        self.step_losses = []  # device scalars of the last `keep_losses` steps (no host sync; diagnostics / parity tests)
+        keep_losses = int(getattr(args, "keep_losses", 64))
         for step in range(0, config.training.n_iters):
             model.train()
             loss = self.unlearn_step(model, optimizer, next(remain_iter), next(forget_iter))
+            self.step_losses.append(loss.detach())
+            if len(self.step_losses) > keep_losses:
+                self.step_losses.pop(0)
+            if ema_helper is not None:
+                ema_helper.update(model)
             if (step + 1) % config.training.log_freq == 0:
                 end = time.time()
                 logging.info(f"step: {step}, loss: {loss.item()}, time: {end - start}")
                 start = time.time()
             if (step + 1) % config.training.snapshot_freq == 0 and sdist.rank() == 0:
                 states = [add_prefix(model.state_dict()), optimizer.state_dict(), step]
+                if ema_helper is not None:
+                    states.append(ema_helper.state_dict())  # reference :607-608
                 torch.save(states, os.path.join(config.ckpt_dir, "ckpt.pth"))
         return model
+
+    def _ema(self, model):
+        """EMAHelper(mu=config.model.ema_rate) registered on the model when config.model.ema is set (reference :205-209)."""
+        if not getattr(self.config.model, "ema", False):
+            return None
+        from ..models.ema import EMAHelper
+        helper = EMAHelper(mu=self.config.model.ema_rate)
+        helper.register(model)
+        return helper
+
+    # ------------------------------------------------------------------ sampling (evaluation of an unlearned model)
+    def sample_image(self, x, model, c, cond_scale, last=True):
+        """Reverse process from noise `x` for classes `c` (reference :828-875): `args.sample_type` "generalized" (DDIM,
+        `args.eta`) or "ddpm_noisy" (ancestral), `args.skip_type` "uniform" | "quad", `args.timesteps` steps.
+        (The reference's "ddpm_noisy" branch imports a misspelt name, `ddpm_steps_conditional`, and fails; here it
+        runs `ddpm_step_conditional`.)  `last=True` keeps only the final state on the device."""
+        from ..functions.denoising import ddpm_step_conditional, generalized_steps_conditional
+        args = self.args
+        if args.skip_type == "uniform":
+            seq = range(0, self.num_timesteps, self.num_timesteps // args.timesteps)
+        elif args.skip_type == "quad":
+            seq = [int(s) for s in list(np.linspace(0, np.sqrt(self.num_timesteps * 0.8), args.timesteps) ** 2)]
+        else:
+            raise NotImplementedError
+        keep = "last" if last else "all"
+        if args.sample_type == "generalized":
+            out = generalized_steps_conditional(x, c, seq, model, self.betas, cond_scale, eta=args.eta, keep=keep)
+        elif args.sample_type == "ddpm_noisy":
+            out = ddpm_step_conditional(x, c, seq, model, self.betas, cond_scale, keep=keep)
+        else:
+            raise NotImplementedError
+        return out[0][-1] if last else out
 
     # ---------------------------------------------- EWC / Selective Amnesia (SURVEY.md §8 F3)
     def forget_step(self, model, optimizer, remember_batch, fisher_flat, params_mle_flat):
@@ -315,8 +356,7 @@ class Diffusion(object):
         model = self._load_model()
         arena = arena_of(model)
         optimizer = get_optimizer(config, arena=arena)
-        if config.model.ema:
-            raise NotImplementedError("EMA is off in the shipped configs (out of scope, SURVEY.md §2 D6)")
+        ema_helper = self._ema(model)
         if fisher_dict is None:
             with open(os.path.join(args.ckpt_folder, "fisher_dict.pkl"), "rb") as f:
                 fisher_dict = pickle.load(f)
@@ -326,11 +366,15 @@ class Diffusion(object):
             model.train()
             loss, forgetting_loss, ewc_loss = self.forget_step(model, optimizer, next(remember_iter), fisher_flat,
                                                                params_mle_flat)
+            if ema_helper is not None:
+                ema_helper.update(model)
             if (step + 1) % config.training.log_freq == 0:
                 logging.info(f"step: {step}, loss: {loss.item()}, forgetting loss: {forgetting_loss.item()}, "
                              f"ewc loss: {ewc_loss.item()}")
             if (step + 1) % config.training.snapshot_freq == 0 and sdist.rank() == 0:
                 states = [add_prefix(model.state_dict()), optimizer.state_dict(), step]
+                if ema_helper is not None:
+                    states.append(ema_helper.state_dict())
                 torch.save(states, os.path.join(config.ckpt_dir, "ckpt.pth"))
         return model
 

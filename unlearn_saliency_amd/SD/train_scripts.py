@@ -3,6 +3,7 @@
     generate_mask / generate_nsfw_mask      SD/train-scripts/generate_mask.py:8-108, :111-211
     certain_label                           SD/train-scripts/random_label.py:13-156
     nsfw_removal                            SD/train-scripts/nsfw_removal.py:33-175
+    proximal_gradient                       SD/train-scripts/proximal_gradient.py:14-186
 
 — with the reference's positional parameters.  Data loaders yield latents + context embeddings
 (ldm_lite.py explains why); `model=` / `*_dl=` keyword arguments inject a prepared model and loaders.
@@ -116,21 +117,28 @@ def _trainable_mask(arena: FlatArena, train_method: str) -> Optional[torch.Tenso
     return m
 
 
-def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_method):
-    """Loop body shared by certain_label / nsfw_removal: forget batches (z, c_forget, c_pseudo), remain batches
-    (z, c); loss = MSE(eps(z_t^f, c_forget), eps(z_t^f, c_pseudo).detach()) + alpha * LDM-loss(remain)."""
+def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_method, proximal_ratio=None):
+    """Loop body shared by certain_label / nsfw_removal / proximal_gradient: forget batches (z, c_forget, c_pseudo),
+    remain batches (z, c); loss = MSE(eps(z_t^f, c_forget), eps(z_t^f, c_pseudo).detach()) + alpha * LDM-loss(remain).
+    `proximal_ratio` (proximal_gradient.py's `mask_ratio`): after every optimizer step the weights are soft-thresholded
+    towards their initial values so that `ratio_t` of them are reset exactly (one diff + select + threshold pass over
+    the flat arena, K9)."""
     arena = _unet_arena(model)
+    init_params = arena.params.clone() if proximal_ratio is not None else None
+    steps_per_epoch = len(forget_dl) + len(remain_dl) if proximal_ratio is not None else 0  # proximal_gradient.py:73
+    total_steps = epochs * steps_per_epoch
     opt = FusedMaskedAdam(arena, lr=lr)  # torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no clipping
     mask_u8 = _trainable_mask(arena, train_method)
     if mask_path:
         saliency = arena.pack_mask(torch.load(mask_path, map_location=arena.device, weights_only=False))
         mask_u8 = saliency if mask_u8 is None else (saliency & mask_u8)
     opt.set_mask(mask_u8)
+    object.__setattr__(model, "_salun_last_optimizer", opt)  # checkpointing / parity tests read the Adam state
     model.train()
     losses = []
-    for _ in range(epochs):
+    for epoch in range(epochs):
         remain_iter = iter(remain_dl)
-        for z_f, c_forget, c_pseudo in forget_dl:
+        for i, (z_f, c_forget, c_pseudo) in enumerate(forget_dl):
             try:
                 z_r, c_r = next(remain_iter)
             except StopIteration:
@@ -149,6 +157,13 @@ def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_me
             loss.backward()
             opt.step()
             losses.append(loss.detach())
+            if proximal_ratio is not None:
+                # proximal_gradient.py:141-176: ratio of weights pulled back onto theta_0, linearly decaying schedule
+                ratio = int(proximal_ratio * ((total_steps - (epoch * steps_per_epoch + i + 1)) / total_steps * arena.n))
+                if ratio >= 1:
+                    ops.proximal_step(arena.params, init_params, ratio)
+                else:
+                    raise IndexError("index -1 is out of bounds for dimension 0 with size 0")  # topk(.., 0)[0][-1]
     model.eval()
     return [float(v) for v in torch.stack(losses).cpu()] if losses else []
 
@@ -160,6 +175,20 @@ def certain_label(class_to_forget, train_method, alpha, batch_size, epochs, lr, 
     if forget_dl is None or remain_dl is None:
         raise ValueError("forget_dl: (latents, class context, pseudo-class context) batches; remain_dl: (latents, context)")
     return model, _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_method)
+
+
+def proximal_gradient(class_to_forget, train_method, alpha, batch_size, epochs, lr, config_path, ckpt_path, mask_ratio,
+                      diffusers_config_path, device, image_size=512, ddim_steps=50, second_device=None, *, model=None,
+                      forget_dl=None, remain_dl=None):
+    """SD/train-scripts/proximal_gradient.py:14-186: random-label unlearning without a saliency mask, followed after
+    every step by the proximal (soft-threshold) pull towards the initial weights with ratio
+    mask_ratio * (remaining steps / total steps) * n_params.  The reference ships the 1-B-parameter vector to a second
+    GPU for the top-k every step (`second_device`, :70-72,157-167); here the select runs in place on the flat arena
+    (`second_device` is accepted and ignored)."""
+    model = model or setup_model(config_path, ckpt_path, device)
+    if forget_dl is None or remain_dl is None:
+        raise ValueError("forget_dl: (latents, class context, pseudo-class context) batches; remain_dl: (latents, context)")
+    return model, _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, None, train_method, proximal_ratio=mask_ratio)
 
 
 def nsfw_removal(train_method, alpha, batch_size, epochs, lr, config_path, ckpt_path, mask_path,

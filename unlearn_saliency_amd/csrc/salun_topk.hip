@@ -82,6 +82,8 @@ struct FastState {
   uint32_t mode[MAXK];   // MODE_NONE or MODE_GE (bracketed)
   uint32_t was_all[MAXK];  // k > n on entry: published as MODE_ALL
   uint32_t lo[MAXK], hi[MAXK], shiftA[MAXK];
+  uint32_t mid[MAXK];    // k_main's guess of the threshold (centre of the bracket): it writes mask = [key > mid] and
+                         // the later kernels touch only the candidates whose final bit differs from that guess
   u64 c_gt[MAXK];        // elements strictly above the bracket
   uint32_t n2[MAXK];     // residents of the chosen first-level bin
   uint32_t lo2[MAXK], hi2[MAXK], shift2[MAXK];
@@ -300,20 +302,57 @@ __global__ __launch_bounds__(1024) void k_bracket(const uint32_t *__restrict__ k
     fs->was_all[tid] = kl.k[tid] > n ? 1u : 0u;
     fs->lo[tid] = lo;
     fs->hi[tid] = hi;
+    fs->mid[tid] = (mode == MODE_GE) ? lo + (hi - lo) / 2 : KEY_SKIP;
     fs->shiftA[tid] = (mode == MODE_GE) ? shift_for(lo, hi, bins_a) : 0;
   }
 }
 
-// Two-level route: the brackets are exact order statistics of the 2^20-element sample (published by the inner
-// selection as thresholds 2j = upper, 2j+1 = lower).
-__global__ __launch_bounds__(1024) void k_bracket_from_inner(const TopkPub *inner, int64_t n, KList kl, RankList rl,
-                                                             int bins_a, FastState *fs, TopkPub *pub, FullState *full) {
-  const int tid = threadIdx.x;
+// Two-level route (n >= 2^27).  The 2^20-element sample is bracketed by its own 16 K sub-sample (k_bracket), streamed
+// once by k_main (values only) and histogrammed by k_hist_a; this kernel then reads, for the two target ranks of
+// every threshold (2j = upper, 2j+1 = lower), the histogram bin holding that rank and takes the bin's OUTER edge as
+// the bracket of the full vector: 1024 bins over ~4.7 % of the sample's mass widen a bracket by < 0.01 % of the mass,
+// against its own width of ~0.6 %.  A rank outside its sample bracket raises `fail` (the full scan takes over).
+__global__ __launch_bounds__(1024) void k_bracket_from_hist(const FastState *inner, int inner_bins, int64_t n, KList kl,
+                                                            RankList rl, int bins_a, FastState *fs, TopkPub *pub,
+                                                            FullState *full) {
+  __shared__ uint32_t s_edge[2 * MAXK];
+  __shared__ uint32_t s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = kl.nk;
   uint32_t *z = reinterpret_cast<uint32_t *>(fs);
   const int words_head = (int)(offsetof(FastState, histA) / 4);
   for (int i = tid; i < words_head; i += 1024) z[i] = 0;
-  if (tid == 0) { full->bar = 0; pub->nk = (uint32_t)nk; pub->error = inner->error; pub->route = 0; }
+  if (tid == 0) { full->bar = 0; pub->nk = (uint32_t)nk; pub->error = 0; pub->route = 0; s_bad = inner->fail; }
+  __syncthreads();
+  for (int q = wave; q < 2 * nk; q += 16) {
+    const bool upper = (q & 1) == 0;
+    const long long want_rank = upper ? rl.hi[q >> 1] : rl.lo[q >> 1];
+    if (want_rank == 0 || inner->mode[q] != MODE_GE) continue;  // unbounded side / trivial threshold
+    const long long r = inner->k[q] - (long long)inner->c_gt[q];
+    const uint32_t *h = inner->histA[q];
+    const int per = inner_bins / 64;
+    u64 mine = 0;
+    for (int i = 0; i < per; ++i) mine += h[inner_bins - 1 - (lane * per + i)];
+    const u64 before = wave_excl_scan_u64(mine, lane);
+    const u64 total = __shfl(before + mine, 63, 64);
+    if (r < 1 || (u64)r > total) { if (lane == 0) s_bad = 1; continue; }
+    if (before < (u64)r && (u64)r <= before + mine) {
+      u64 cum = before;
+      for (int i = 0; i < per; ++i) {
+        const int bin = inner_bins - 1 - (lane * per + i);
+        const u64 c = h[bin];
+        if ((u64)r <= cum + c) {
+          const uint32_t sh = inner->shiftA[q];
+          const uint32_t lo_edge = inner->lo[q] + ((uint32_t)bin << sh);
+          uint32_t hi_edge = lo_edge + ((1u << sh) - 1u);
+          if (hi_edge > inner->hi[q] || hi_edge < lo_edge) hi_edge = inner->hi[q];
+          s_edge[q] = upper ? hi_edge : lo_edge;
+          break;
+        }
+        cum += c;
+      }
+    }
+  }
   __syncthreads();
   if (tid < nk) {
     long long k = kl.k[tid];
@@ -323,25 +362,35 @@ __global__ __launch_bounds__(1024) void k_bracket_from_inner(const TopkPub *inne
       k = 0; mode = MODE_NONE; lo = hi = KEY_SKIP;
     } else {
       mode = MODE_GE;
-      hi = rl.hi[tid] ? inner->tau[2 * tid] : KEY_MAX;
-      lo = rl.lo[tid] ? inner->tau[2 * tid + 1] : 0u;
+      hi = rl.hi[tid] ? s_edge[2 * tid] : KEY_MAX;
+      lo = rl.lo[tid] ? s_edge[2 * tid + 1] : 0u;
       if (hi > KEY_MAX) hi = KEY_MAX;
-      if (lo > hi) lo = hi;  // cannot happen for a valid inner selection; keeps the arithmetic below in range
+      if (lo > hi) lo = hi;  // cannot happen for valid sample brackets; keeps the arithmetic below in range
     }
     fs->k[tid] = k;
     fs->mode[tid] = mode;
     fs->was_all[tid] = kl.k[tid] > n ? 1u : 0u;
     fs->lo[tid] = lo;
     fs->hi[tid] = hi;
+    fs->mid[tid] = (mode == MODE_GE) ? lo + (hi - lo) / 2 : KEY_SKIP;
     fs->shiftA[tid] = (mode == MODE_GE) ? shift_for(lo, hi, bins_a) : 0;
   }
+  __syncthreads();
+  if (tid == 0 && s_bad) fs->fail = 1;
 }
 
+// The 2^20-element sample of the two-level route (values, for k_main) and, in the same launch, its 16 K-element
+// sub-sample (keys, for k_bracket): window w of `sub` consecutive samples contributes the one at a hashed offset.
 __global__ __launch_bounds__(SALUN_BLOCK) void k_gather_sample(const float *__restrict__ acc, int64_t stride, int64_t S,
-                                                               float *__restrict__ out) {
+                                                               float *__restrict__ out, int sub,
+                                                               uint32_t *__restrict__ keys) {
   const int64_t s = (int64_t)blockIdx.x * SALUN_BLOCK + threadIdx.x;
-  if (s < S) out[s] = acc[s * stride + (int64_t)__umulhi((uint32_t)salun_splitmix64((uint64_t)s ^ 0x5bd1e995ull),
-                                                         (uint32_t)stride)];
+  if (s >= S) return;
+  const float v = acc[s * stride + (int64_t)__umulhi((uint32_t)salun_splitmix64((uint64_t)s ^ 0x5bd1e995ull),
+                                                     (uint32_t)stride)];
+  out[s] = v;
+  const int64_t w = s / sub;
+  if ((int64_t)__umulhi((uint32_t)salun_splitmix64((uint64_t)w), (uint32_t)sub) == s - w * sub) keys[w] = key_of(v);
 }
 
 // -------------------------------------------------------------------------------------- k_main
@@ -367,12 +416,13 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
       if (i < wa) za[i] = 0; else z2[i - wa] = 0;
     }
   }
-  uint32_t hi[NK], lo[NK], gtc[NK];
+  uint32_t hi[NK], lo[NK], mid[NK], gtc[NK];
 #pragma unroll
   for (int j = 0; j < NK; ++j) {
     hi[j] = (j < nk_real) ? fs->hi[j] : KEY_SKIP;
     lo[j] = (j < nk_real) ? fs->lo[j] : KEY_SKIP;
-    gtc[j] = 0;
+    mid[j] = (j < nk_real) ? fs->mid[j] : KEY_SKIP;
+    gtc[j] = 0;  // wave-uniform count of keys above the bracket
   }
   __syncthreads();
   const int64_t nfull = n / CHUNK;
@@ -395,11 +445,11 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
         uint32_t bits = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          bits |= (uint32_t)(k[u][e] > hi[j]) << (8 * e);
+          bits |= (uint32_t)(k[u][e] > mid[j]) << (8 * e);
           bal[u * 4 + e] = __builtin_amdgcn_ballot_w64((k[u][e] - lo[j]) <= w);
           total += (uint32_t)__builtin_popcountll(bal[u * 4 + e]);
+          gtc[j] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(k[u][e] > hi[j]));
         }
-        gtc[j] += (uint32_t)__builtin_popcount(bits);
         if (!VO)
           __builtin_nontemporal_store(bits, reinterpret_cast<uint32_t *>(mp.m[j]) + c * CHUNK_VEC + u * SALUN_BLOCK + tid);
       }
@@ -426,15 +476,17 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
     }
   }
   // ragged tail (n % 4096 elements): one workgroup, element-wise
+  uint32_t tail_gt[NK];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) tail_gt[j] = 0;
   if ((int64_t)blockIdx.x == nfull % (int64_t)gridDim.x) {
     for (int64_t i = nfull * CHUNK + tid; i < n; i += SALUN_BLOCK) {
       const uint32_t key = key_of(acc[i]);
 #pragma unroll
       for (int j = 0; j < NK; ++j) {
         if (j >= nk_real) continue;
-        const uint32_t gt = key > hi[j];
-        gtc[j] += gt;
-        if (!VO) mp.m[j][i] = (uint8_t)gt;
+        tail_gt[j] += key > hi[j];
+        if (!VO) mp.m[j][i] = (uint8_t)(key > mid[j]);
         if ((key - lo[j]) <= (hi[j] - lo[j])) {
           const uint32_t pos = atomicAdd(&s_cnt[j], 1u);
           if (pos < cap)
@@ -445,9 +497,9 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
   }
 #pragma unroll
   for (int j = 0; j < NK; ++j) {
-    uint32_t v = gtc[j];
+    uint32_t v = tail_gt[j];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) s_gt[wave][j] = v;
+    if (lane == 0) s_gt[wave][j] = v + gtc[j];
   }
   __syncthreads();
   if (tid < nk_real) {
@@ -555,7 +607,8 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
   }
   __syncthreads();
   if (s_ok) {
-    const uint32_t lo2 = s_lo2, hi2 = s_hi2, sh2 = s_sh2;
+    const uint32_t lo2 = s_lo2, hi2 = s_hi2, sh2 = s_sh2, mid = fs->mid[j];
+    (void)mid;
     uint8_t *mask = mp.m[j];
     const int waves = nseg * 16;
     const int spr = waves > main_grid ? waves / main_grid : 1;  // waves sharing one slab row
@@ -566,8 +619,9 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
       const uint2 *slab = slabs + r * cap;
       for (uint32_t i = part * 64 + lane; i < cnt; i += 64 * spr) {
         const uint2 e = slab[i];
-        if (e.x > hi2) { if (!VO) mask[e.y] = 1; }
-        else if (e.x >= lo2) {
+        if (e.x > hi2) { if (!VO && e.x <= mid) mask[e.y] = 1; }       // selected for good; k_main guessed 0
+        else if (e.x < lo2) { if (!VO && e.x > mid) mask[e.y] = 0; }   // rejected for good; k_main guessed 1
+        else {
           atomicAdd(&fs->hist2[j][(e.x - lo2) >> sh2], 1u);
           const uint32_t p = atomicAdd(&s_n, 1u);
           if (p < (uint32_t)STAGE_CAP) s_stage[p] = e;
@@ -669,12 +723,14 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
   const uint32_t r3 = s_r3, c3 = s_c3;
   const uint2 *lst = list2 + (size_t)j * nseg * STAGE_CAP;
   uint8_t *mask = mp.m[j];
+  const uint32_t mid = fs->mid[j];  // k_main wrote [key > mid]
   const uint32_t all_mode = fs->was_all[j] ? MODE_ALL : MODE_GE;
   if (c3 <= (uint32_t)FINAL_CAP) {
     for (uint32_t f = tid; f < n2; f += 1024) {
       const uint2 e = list_entry(lst, s_off, nseg, f);
-      if (e.x > hi3) { if (!VO) mask[e.y] = 1; }
-      else if (e.x >= lo3) {
+      if (e.x > hi3) { if (!VO && e.x <= mid) mask[e.y] = 1; }
+      else if (e.x < lo3) { if (!VO && e.x > mid) mask[e.y] = 0; }
+      else {
         const uint32_t p = atomicAdd(&s_n, 1u);
         if (p < (uint32_t)FINAL_CAP) { s_key[p] = e.x; s_idx[p] = e.y; }
       }
@@ -686,7 +742,7 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
       const uint32_t kp = s_key[p], ip = s_idx[p];
       uint32_t rank = 0;
       for (uint32_t q = 0; q < L; ++q) rank += (s_key[q] > kp) || (s_key[q] == kp && s_idx[q] < ip);
-      if (rank < r3 && !VO) mask[ip] = 1;
+      if (!VO && (rank < r3) != (kp > mid)) mask[ip] = (uint8_t)(rank < r3);
       if (rank == r3 - 1) s_tau = kp;
     }
     __syncthreads();
@@ -728,7 +784,8 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
   if (!VO)
     for (uint32_t f = tid; f < n2; f += 1024) {
       const uint2 e = list_entry(lst, s_off, nseg, f);
-      if (e.x > hi3 || (e.x == lo3 && e.y <= idx_star)) mask[e.y] = 1;
+      const bool fin = e.x > hi3 || (e.x == lo3 && e.y <= idx_star);
+      if (fin != (e.x > mid)) mask[e.y] = (uint8_t)fin;
     }
   if (tid == 0) { pub->mode[j] = all_mode; pub->tau[j] = lo3; pub->route = 1; }
 }
@@ -1419,21 +1476,28 @@ SALUN_EXPORT int salun_mask_topk_ex(const float *acc, int64_t n, const int64_t *
       k2.k[2 * j] = rhi ? rhi : 1;       // unbounded sides are not read back
       k2.k[2 * j + 1] = rlo ? rlo : 1;
     }
-    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)(S2 / SALUN_BLOCK)), dim3(SALUN_BLOCK), 0, st, acc, n / S2, S2, samp);
-    SALUN_LAUNCH_CHECK();
     const int S1 = sample_size(S2);
     uint32_t *ikeys = reinterpret_cast<uint32_t *>(ifast + W.inner.off_keys);
-    hipLaunchKernelGGL(k_sample, dim3(S1 / 1024), dim3(1024), 0, st, samp, S2, S1, ikeys);
+    hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)(S2 / SALUN_BLOCK)), dim3(SALUN_BLOCK), 0, st, acc, n / S2, S2, samp,
+                       (int)(S2 / S1), ikeys);
     SALUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bracket, dim3(1), dim3(1024), 0, st, ikeys, S2, k2, S1, bins_a_for(2 * nk), ifs, ipub, ifull);
+    const int ibins = bins_a_for(2 * nk);
+    hipLaunchKernelGGL(k_bracket, dim3(1), dim3(1024), 0, st, ikeys, S2, k2, S1, ibins, ifs, ipub, ifull);
     SALUN_LAUNCH_CHECK();
-    MaskPtrs none;
-    for (int j = 0; j < MAXK; ++j) none.m[j] = nullptr;
-    u64 *itie = tie;  // the sample has fewer chunks than the vector: the outer rows are large enough and not yet in use
-    if ((size_t)(2 * nk) * (size_t)(chunks_of(S2) + 1) > (size_t)nk * (size_t)(chunks_of(n) + 1)) return SALUN_EINVAL;
-    int rc = run_fast_tail(samp, S2, k2, none, true, ifast, W.inner, ipub, ifull, itie, true, true, st);
-    if (rc != SALUN_OK) return rc;
-    hipLaunchKernelGGL(k_bracket_from_inner, dim3(1), dim3(1024), 0, st, ipub, n, kl, rl, bins_a, fs, pub, full);
+    {  // the sample's streaming pass + candidate histogram; its resolution stops there (k_bracket_from_hist)
+      const FastLayout &L = W.inner;
+      uint32_t *slab_cnt = reinterpret_cast<uint32_t *>(ifast + L.off_cnt);
+      uint32_t *wg_gt = reinterpret_cast<uint32_t *>(ifast + L.off_gt);
+      uint2 *slabs = reinterpret_cast<uint2 *>(ifast + L.off_slabs);
+      MaskPtrs none;
+      for (int j = 0; j < MAXK; ++j) none.m[j] = nullptr;
+      launch_main<true>(2 * nk, L.grid, st, samp, S2, ifs, none, slabs, slab_cnt, wg_gt, L.cap, ibins);
+      SALUN_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_hist_a, dim3(L.ga), dim3(1024), sizeof(uint32_t) * (size_t)(2 * nk) * ibins, st, ifs, slabs,
+                         slab_cnt, wg_gt, L.cap, L.grid, 2 * nk, ibins);
+      SALUN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_bracket_from_hist, dim3(1), dim3(1024), 0, st, ifs, ibins, n, kl, rl, bins_a, fs, pub, full);
     SALUN_LAUNCH_CHECK();
   }
   return run_fast_tail(acc, n, kl, mp, values_only, fast_base, W.outer, pub, full, tie, aligned, maligned, st);

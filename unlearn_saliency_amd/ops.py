@@ -383,8 +383,8 @@ def proximal_step(p: torch.Tensor, p0: torch.Tensor, ratio: int, scratch: Option
     d = scratch if scratch is not None else torch.empty(n, dtype=torch.float32, device=p.device)
     check(L.salun_param_diff(_dev(p, torch.float32, "p"), _dev(p0, torch.float32, "p0"), _dev(d, torch.float32, "d"),
                              c_int64(n), _stream()), "salun_param_diff")
-    m = scratch_mask if scratch_mask is not None else torch.empty(n, dtype=torch.uint8, device=p.device)
-    mask_topk(d, [n - ratio + 1], out=[m])  # k-th largest |d| with k = n - ratio + 1 == ratio-th smallest
+    # k-th largest |d| with k = n - ratio + 1 == ratio-th smallest; only the threshold is needed: no mask is written
+    mask_topk(d, [n - ratio + 1], flags=_lib.SALUN_TOPK_VALUES_ONLY)
     tau = mask_topk_thresholds(p.device, 1)
     check(L.salun_soft_threshold_step(_dev(p, torch.float32, "p"), _dev(p0, torch.float32, "p0"),
                                       c_void_p(tau.data_ptr()), c_int64(n), _stream()), "salun_soft_threshold_step")

@@ -317,7 +317,8 @@ def main():
             pth = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if os.path.exists(pth):
                 with open(pth) as f:
-                    pmc_traffic = json.load(f)["kernels"]["k_masked_sgd_vec@n18"]["traffic_bytes"]
+                    kern = json.load(f)["kernels"]
+                pmc_traffic = (kern.get(f"k_masked_sgd_vec@{rnd}_n18") or kern["k_masked_sgd_vec@n18"])["traffic_bytes"]
                 pmc_src = (f"profiles/{rnd}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
                            f"passes over tools/kbench.py, tools/pmc.sh; PMC cannot be collected inside this run)")
                 break

@@ -43,5 +43,45 @@ def make_sd():
     print("sd fixtures written")
 
 
+def make_convert():
+    """Key layout produced by the REFERENCE's convert_ldm_unet_checkpoint (SD/train-scripts/convertModels.py:348-591;
+    diffusers / omegaconf are stubbed: the function only renames keys): tiny config with per-tensor checksums, full
+    v1 config as the ordered key list."""
+    import types
+    from types import SimpleNamespace
+    for m in ("omegaconf", "diffusers", "diffusers.pipelines", "diffusers.pipelines.latent_diffusion",
+              "diffusers.pipelines.latent_diffusion.pipeline_latent_diffusion", "diffusers.pipelines.paint_by_example",
+              "diffusers.pipelines.stable_diffusion"):
+        _stub(m)
+    sys.modules["omegaconf"].OmegaConf = type("OmegaConf", (), {})
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, n):
+            return type(n, (), {})
+    for m in list(sys.modules):
+        if m == "diffusers" or m.startswith("diffusers."):
+            sys.modules[m].__class__ = _Any
+    sys.path.insert(0, "/root/reference/SD/train-scripts")
+    import convertModels as CM
+    from unlearn_saliency_amd.SD.unet import UNetModel, V1_UNET_CONFIG
+    out = {}
+    cfg = sd_tiny_config()
+    m = fill_params(UNetModel(**cfg), 9000)
+    sd = {"model.diffusion_model." + k: v for k, v in m.state_dict().items()}
+    conv = CM.convert_ldm_unet_checkpoint(dict(sd), {"layers_per_block": cfg["num_res_blocks"]})
+    out["tiny_keys"] = np.array(list(conv.keys()))
+    out["tiny_sums"] = np.array([float(v.double().sum()) for v in conv.values()])
+    out["tiny_shapes"] = np.array([str(tuple(v.shape)) for v in conv.values()])
+    with torch.device("meta"):
+        full = UNetModel(**V1_UNET_CONFIG)
+    sdf = {"model.diffusion_model." + k: v for k, v in full.state_dict().items()}
+    convf = CM.convert_ldm_unet_checkpoint(dict(sdf), {"layers_per_block": V1_UNET_CONFIG["num_res_blocks"]})
+    out["full_keys_sorted"] = np.array(sorted(convf.keys()))
+    out["full_shapes_sorted"] = np.array([str(tuple(convf[k].shape)) for k in sorted(convf.keys())])
+    np.savez_compressed(os.path.join(HERE, "sd_convert.npz"), **out)
+    print("sd convert fixtures written:", len(conv), "tiny keys,", len(convf), "full keys")
+
+
 if __name__ == "__main__":
     make_sd()
+    make_convert()

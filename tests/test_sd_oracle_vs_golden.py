@@ -35,3 +35,26 @@ def test_ldm_schedule_and_prefix():
     names = [n for n, _ in m.named_parameters()]
     assert all(n.startswith("model.diffusion_model.") for n in names)
     assert names[0].split("model.diffusion_model.")[-1] == "time_embed.0.weight"
+
+
+def test_compvis_to_diffusers_key_layout_matches_reference(golden_dir):
+    """SD/convert.py against the REFERENCE's convert_ldm_unet_checkpoint (convertModels.py:348-591): same keys and the
+    same tensor behind every key on the tiny configuration; same key set and shapes on the full v1 U-Net."""
+    from unlearn_saliency_amd.SD.convert import convert_ldm_unet_checkpoint
+    from unlearn_saliency_amd.SD.unet import UNetModel, V1_UNET_CONFIG
+    g = np.load(os.path.join(golden_dir, "sd_convert.npz"))
+    cfg = sd_tiny_config()
+    m = fill_params(UNetModel(**cfg), 9000)
+    sd = {"model.diffusion_model." + k: v for k, v in m.state_dict().items()}
+    sd["first_stage_model.ignored"] = torch.zeros(1)
+    conv = convert_ldm_unet_checkpoint(sd, cfg["num_res_blocks"])
+    ref = dict(zip(g["tiny_keys"], zip(g["tiny_sums"], g["tiny_shapes"])))
+    assert set(conv) == set(ref) and len(conv) == len(ref)
+    for k, v in conv.items():
+        assert str(tuple(v.shape)) == ref[k][1], k
+        assert abs(float(v.double().sum()) - float(ref[k][0])) <= 1e-9 * max(1.0, abs(float(ref[k][0]))), k
+    with torch.device("meta"):
+        full = UNetModel(**V1_UNET_CONFIG)
+    convf = convert_ldm_unet_checkpoint(full.state_dict(), V1_UNET_CONFIG["num_res_blocks"])
+    assert sorted(convf) == list(g["full_keys_sorted"])
+    assert [str(tuple(convf[k].shape)) for k in sorted(convf)] == list(g["full_shapes_sorted"])

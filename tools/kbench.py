@@ -37,7 +37,9 @@ def run(n, iters, nk_list=(1, 10)):
     p = ops.fill_normal(n, 1, 0, 0.05)
     g = ops.fill_normal(n, 2, 0, 1e-3)
     buf = torch.zeros(n, device="cuda")
-    acc = ops.fill_normal(n, 3, 0, 1e-3)
+    # high-entropy magnitudes (the plain Irwin-Hall normal has < 8e5 distinct values: every threshold would sit in a
+    # long run of ties)
+    acc = ops.fill_normal(n, 3, 0, 1e-3) * (1.0 + ops.fill_uniform(n, 4, 0.0, 0.5))
     m = ops.mask_topk(acc, [n // 2])[0]
 
     def rec(name, sec, bytes_per_elem):

@@ -521,6 +521,7 @@ __global__ __launch_bounds__(1024) void k_hist_a(FastState *fs, const uint2 *__r
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ u64 s_red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (fs->fail) return;  // a slab overflowed in k_main (heavy ties): the full scan redoes the job
   for (int i = tid; i < nk * bins_a; i += 1024) lds[i] = 0;
   __syncthreads();
   const int rows = main_grid * nk;
@@ -567,10 +568,14 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
                                                   uint32_t *__restrict__ seg_cnt /*[nk][nseg]*/, MaskPtrs mp) {
   __shared__ uint32_t s_lo2, s_hi2, s_sh2, s_ok;
   __shared__ uint2 s_stage[STAGE_CAP];
+  __shared__ uint32_t s_h2[HIST2_BINS];  // this workgroup's share of the 4096-bin histogram: a run of equal keys
+                                         // would otherwise serialise ~12 ns global atomics on ONE address
   __shared__ uint32_t s_n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = blockIdx.x % nk, g = blockIdx.x / nk;  // workgroup g of the nseg that serve threshold j
+  if (fs->fail) return;  // already decided (slab overflow): the full scan redoes the job
   if (tid == 0) { s_n = 0; s_ok = 0; }
+  for (int i = tid; i < HIST2_BINS; i += 1024) s_h2[i] = 0;
   __syncthreads();
   if (wave == 0 && fs->mode[j] == MODE_GE) {
     const long long r = fs->k[j] - (long long)fs->c_gt[j];  // rank wanted among the candidates, 1-based descending
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
         if (e.x > hi2) { if (!VO && e.x <= mid) mask[e.y] = 1; }       // selected for good; k_main guessed 0
         else if (e.x < lo2) { if (!VO && e.x > mid) mask[e.y] = 0; }   // rejected for good; k_main guessed 1
         else {
-          atomicAdd(&fs->hist2[j][(e.x - lo2) >> sh2], 1u);
+          atomicAdd(&s_h2[(e.x - lo2) >> sh2], 1u);
           const uint32_t p = atomicAdd(&s_n, 1u);
           if (p < (uint32_t)STAGE_CAP) s_stage[p] = e;
         }
@@ -630,6 +635,9 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
     }
   }
   __syncthreads();
+  if (s_n)
+    for (int i = tid; i < HIST2_BINS; i += 1024)
+      if (s_h2[i]) atomicAdd(&fs->hist2[j][i], s_h2[i]);
   const uint32_t m = s_n;
   const uint32_t keep = m < (uint32_t)STAGE_CAP ? m : (uint32_t)STAGE_CAP;
   uint2 *seg = list2 + ((size_t)j * nseg + g) * STAGE_CAP;

@@ -69,7 +69,7 @@ struct PatchPos {
 // `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
 // STRIDE and the padding is R-1-pad.
 template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST>
-__global__ __launch_bounds__(256) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
+__global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
                                                   const float *__restrict__ bias, float *__restrict__ y, int N,
                                                   int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
                                                   int TP, int IH_t, int IW_t, int logQ, int wC /*w dim1 (C of OIHW)*/,
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
 // insertion, one launch instead of four, and the epilogue writes (2b, 2b+1) pairs: full coalesced rows of dX.
 // (The per-class conv_igemm_tap path stays as the fallback for shapes outside this kernel's staging assumptions.)
 template <int R, int PAD, int KT, int WP, int WK>
-__global__ __launch_bounds__(256) void conv_dgrad_s2(const float *__restrict__ dy, const float *__restrict__ w,
+__global__ __launch_bounds__(256, 2) void conv_dgrad_s2(const float *__restrict__ dy, const float *__restrict__ w,
                                                      const float *__restrict__ addend, float *__restrict__ dx, int N,
                                                      int K, int P, int Q, int C, int H, int W, int NI, int TP,
                                                      int IH_t, int IW_t, int logQ) {

@@ -154,11 +154,22 @@ __device__ __forceinline__ uint32_t shift_for(uint32_t lo, uint32_t hi, int bins
   return s;
 }
 
+// Workgroup 0 of the sampling kernel clears the small head of the state and the publication block for this call
+// (the histograms are zeroed by k_main's workgroups); k_bracket's workgroups then fill in one threshold each.
+__device__ __forceinline__ void reset_head(FastState *fs, TopkPub *pub, FullState *full, int nk, int tid, int nthreads) {
+  uint32_t *z = reinterpret_cast<uint32_t *>(fs);
+  const int words_head = (int)(offsetof(FastState, histA) / 4);
+  for (int i = tid; i < words_head; i += nthreads) z[i] = 0;
+  if (tid == 0) { full->bar = 0; pub->nk = (uint32_t)nk; pub->error = 0; pub->route = 0; }
+}
+
 // The sample: one element per stride window at a hashed offset (a fixed offset would lock onto periodic structure of
 // the flat vector, e.g. always the centre tap of 3x3 kernels).  Spread over S/1024 workgroups: 16 K random cache lines
 // are more than one CU can pull in a few microseconds.  Writes the KEYS, coalesced.
 __global__ __launch_bounds__(1024) void k_sample(const float *__restrict__ acc, int64_t n, int S,
-                                                 uint32_t *__restrict__ keys) {
+                                                 uint32_t *__restrict__ keys, FastState *fs, TopkPub *pub,
+                                                 FullState *full, int nk) {
+  if (blockIdx.x == 0) reset_head(fs, pub, full, nk, threadIdx.x, 1024);
   const int64_t stride = n / S;  // < 2^31: the offset inside a window is a 32-bit multiply-high, not a 64-bit modulo
   const int64_t s = (int64_t)blockIdx.x * 1024 + threadIdx.x;
   if (s < S) {
@@ -180,20 +191,16 @@ __global__ __launch_bounds__(1024) void k_bracket(const uint32_t *__restrict__ k
   __shared__ uint32_t s_gprefix[2 * MAXK];
   uint32_t *h0 = h0c[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nk = kl.nk;
-  // ---- zero the small head of the state (the histograms are zeroed by k_main's workgroups)
-  {
-    uint32_t *z = reinterpret_cast<uint32_t *>(fs);
-    const int words_head = (int)(offsetof(FastState, histA) / 4);
-    for (int i = tid; i < words_head; i += 1024) z[i] = 0;
-    if (tid == 0) { full->bar = 0; pub->nk = (uint32_t)nk; pub->error = 0; pub->route = 0; }
-  }
+  // One workgroup per threshold (every workgroup histograms the whole sample: 64 KB out of L2); a one-workgroup
+  // launch serves all of them.  The head of the state was cleared by the sampling kernel.
+  const int nk = gridDim.x > 1 ? 1 : kl.nk;
+  const int j0 = gridDim.x > 1 ? (int)blockIdx.x : 0;
   for (int i = tid; i < H0_COPIES * D0_BINS; i += 1024) (&h0c[0][0])[i] = 0;
   for (int i = tid; i < D0_BINS; i += 1024) lut[i] = 0;
-  for (int i = tid; i < 2 * MAXK * 256; i += 1024) (&h1[0][0])[i] = 0;
+  for (int i = tid; i < 2 * nk * 256; i += 1024) (&h1[0][0])[i] = 0;
   // ---- target ranks
   if (tid < nk) {
-    long long k = kl.k[tid];
+    long long k = kl.k[j0 + tid];
     if (k > n) k = n;
     long long rhi = 0, rlo = 0;
     if (k > 0) {
@@ -286,7 +293,8 @@ __global__ __launch_bounds__(1024) void k_bracket(const uint32_t *__restrict__ k
   }
   __syncthreads();
   if (tid < nk) {
-    long long k = kl.k[tid];
+    const int j = j0 + tid;
+    long long k = kl.k[j];
     if (k > n) k = n;
     uint32_t lo, hi, mode;
     if (k <= 0) {
@@ -297,13 +305,13 @@ __global__ __launch_bounds__(1024) void k_bracket(const uint32_t *__restrict__ k
       lo = s_rank[2 * tid + 1] ? ((s_b0[2 * tid + 1] << 20) | (s_b1[2 * tid + 1] << 12)) : 0u;
       if (hi > KEY_MAX) hi = KEY_MAX;
     }
-    fs->k[tid] = k;
-    fs->mode[tid] = mode;
-    fs->was_all[tid] = kl.k[tid] > n ? 1u : 0u;
-    fs->lo[tid] = lo;
-    fs->hi[tid] = hi;
-    fs->mid[tid] = (mode == MODE_GE) ? lo + (hi - lo) / 2 : KEY_SKIP;
-    fs->shiftA[tid] = (mode == MODE_GE) ? shift_for(lo, hi, bins_a) : 0;
+    fs->k[j] = k;
+    fs->mode[j] = mode;
+    fs->was_all[j] = kl.k[j] > n ? 1u : 0u;
+    fs->lo[j] = lo;
+    fs->hi[j] = hi;
+    fs->mid[j] = (mode == MODE_GE) ? lo + (hi - lo) / 2 : KEY_SKIP;
+    fs->shiftA[j] = (mode == MODE_GE) ? shift_for(lo, hi, bins_a) : 0;
   }
 }
 
@@ -383,7 +391,9 @@ __global__ __launch_bounds__(1024) void k_bracket_from_hist(const FastState *inn
 // sub-sample (keys, for k_bracket): window w of `sub` consecutive samples contributes the one at a hashed offset.
 __global__ __launch_bounds__(SALUN_BLOCK) void k_gather_sample(const float *__restrict__ acc, int64_t stride, int64_t S,
                                                                float *__restrict__ out, int sub,
-                                                               uint32_t *__restrict__ keys) {
+                                                               uint32_t *__restrict__ keys, FastState *fs, TopkPub *pub,
+                                                               FullState *full, int nk) {
+  if (blockIdx.x == 0) reset_head(fs, pub, full, nk, threadIdx.x, SALUN_BLOCK);
   const int64_t s = (int64_t)blockIdx.x * SALUN_BLOCK + threadIdx.x;
   if (s >= S) return;
   const float v = acc[s * stride + (int64_t)__umulhi((uint32_t)salun_splitmix64((uint64_t)s ^ 0x5bd1e995ull),
@@ -1454,9 +1464,9 @@ SALUN_EXPORT int salun_mask_topk_ex(const float *acc, int64_t n, const int64_t *
   if (!two_level) {
     const int S = sample_size(n);
     uint32_t *skeys = reinterpret_cast<uint32_t *>(fast_base + W.outer.off_keys);
-    hipLaunchKernelGGL(k_sample, dim3(S / 1024), dim3(1024), 0, st, acc, n, S, skeys);
+    hipLaunchKernelGGL(k_sample, dim3(S / 1024), dim3(1024), 0, st, acc, n, S, skeys, fs, pub, full, nk);
     SALUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bracket, dim3(1), dim3(1024), 0, st, skeys, n, kl, S, bins_a, fs, pub, full);
+    hipLaunchKernelGGL(k_bracket, dim3(nk), dim3(1024), 0, st, skeys, n, kl, S, bins_a, fs, pub, full);
     SALUN_LAUNCH_CHECK();
   } else {
     // ---- brackets = exact order statistics of a 2^20-element sample (this same route on the sample, values only)
@@ -1487,10 +1497,10 @@ SALUN_EXPORT int salun_mask_topk_ex(const float *acc, int64_t n, const int64_t *
     const int S1 = sample_size(S2);
     uint32_t *ikeys = reinterpret_cast<uint32_t *>(ifast + W.inner.off_keys);
     hipLaunchKernelGGL(k_gather_sample, dim3((unsigned)(S2 / SALUN_BLOCK)), dim3(SALUN_BLOCK), 0, st, acc, n / S2, S2, samp,
-                       (int)(S2 / S1), ikeys);
+                       (int)(S2 / S1), ikeys, ifs, ipub, ifull, 2 * nk);
     SALUN_LAUNCH_CHECK();
     const int ibins = bins_a_for(2 * nk);
-    hipLaunchKernelGGL(k_bracket, dim3(1), dim3(1024), 0, st, ikeys, S2, k2, S1, ibins, ifs, ipub, ifull);
+    hipLaunchKernelGGL(k_bracket, dim3(2 * nk), dim3(1024), 0, st, ikeys, S2, k2, S1, ibins, ifs, ipub, ifull);
     SALUN_LAUNCH_CHECK();
     {  // the sample's streaming pass + candidate histogram; its resolution stops there (k_bracket_from_hist)
       const FastLayout &L = W.inner;

@@ -236,6 +236,41 @@ int salun_conv2d_backward_weight(const float *x /*dev*/, const float *dy /*dev*/
                                  int H, int W, int K, int R, int stride, int pad, int P, int Q, int accumulate,
                                  void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 
+/* ------------------------------------------------------------------ K11 --
+ * bf16 2-D convolution on the matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulators): the convolutions of the
+ * Stable-Diffusion U-Net in its bf16 configuration (BASELINE.json configs[4]) — replaces the library calls autograd
+ * issues under autocast for the `conv_nd(2, ...)` modules of
+ *   SD/ldm/modules/diffusionmodules/openaimodel.py:98-103 (Upsample), :131-133 (Downsample), :192-231 (ResBlock),
+ *   :466-470,:716-720 (input / output heads) and SD/ldm/modules/attention.py:230-247 (proj_in / proj_out).
+ * Activations are NHWC bf16 (`uint16_t` = raw bf16 bits): x[N][H][W][C], y[N][OH][OW][K]; the master weights stay
+ * fp32 OIHW in the flat arena and `salun_conv2d_bf16_pack_weights` writes the bf16 image wp[K][R*R][C] both
+ * data kernels read (backward-data reads it transposed, no second image).  Square filter R in {1,3}, stride in
+ * {1,2}, symmetric padding <= R-1, C % 32 == 0, K % 32 == 0, 16-B aligned pointers;
+ * anything else returns SALUN_EINVAL (`salun_conv2d_bf16_supported` answers without launching).
+ *   forward         y = conv(x, w) + bias[k] + nbias[n][k] + addend[n][oh][ow][k]   (each optional, fp32 / fp32 / bf16)
+ *   backward_data   dx = conv_transpose(dy, w) + addend[n][h][w][c]
+ *   backward_weight dw[K][C][R][R] fp32 (= or +=): sum over pixels of dy * x, pixel range split over workgroups ->
+ *                   fp32 partials in `ws` -> fixed-order reduce (deterministic); db[K] fp32 (optional) = sum of dy. */
+int salun_conv2d_bf16_supported(int C, int K, int R, int stride, int pad);
+int salun_conv2d_bf16_pack_weights(const float *w /*dev, OIHW*/, uint16_t *wp /*dev*/, int K, int C, int R,
+                                   salun_stream_t stream);
+/* `ws` of forward / backward_data (salun_conv2d_bf16_data_workspace_bytes, may be 0): problems with few output tiles
+ * split their reduction over workgroups through fp32 partial tiles there; NULL / too small only disables the split. */
+size_t salun_conv2d_bf16_data_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad);
+int salun_conv2d_bf16_forward(const uint16_t *x /*dev*/, const uint16_t *wp /*dev*/, const float *bias /*dev or NULL*/,
+                              const float *nbias /*dev or NULL*/, const uint16_t *addend /*dev or NULL*/,
+                              uint16_t *y /*dev*/, int N, int H, int W, int C, int K, int R, int stride, int pad,
+                              void *ws /*dev or NULL*/, size_t ws_bytes, salun_stream_t stream);
+int salun_conv2d_bf16_backward_data(const uint16_t *dy /*dev*/, const uint16_t *wp /*dev*/,
+                                    const uint16_t *addend /*dev or NULL*/, uint16_t *dx /*dev*/, int N, int H, int W,
+                                    int C, int K, int R, int stride, int pad, void *ws /*dev or NULL*/, size_t ws_bytes,
+                                    salun_stream_t stream);
+size_t salun_conv2d_bf16_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad);
+int salun_conv2d_bf16_backward_weight(const uint16_t *x /*dev*/, const uint16_t *dy /*dev*/, float *dw /*dev*/,
+                                      float *db /*dev or NULL*/, int N, int H, int W, int C, int K, int R, int stride,
+                                      int pad, int accumulate, void *ws /*dev*/, size_t ws_bytes,
+                                      salun_stream_t stream);
+
 /* Fused BatchNorm2d (+ residual add) (+ ReLU), NCHW fp32, forward and backward — replaces the
  * bn -> relu / bn -> (+identity) -> relu chains of the classifier blocks
  *   (Classification/models/ResNet.py:108-125,307-309) that run as separate library launches.

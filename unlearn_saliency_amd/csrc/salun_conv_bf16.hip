@@ -1,0 +1,664 @@
+// salun_conv_bf16.hip — K11: bf16 2-D convolution forward / backward-data / backward-weight as implicit GEMM on the
+// CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16: 8 bf16 per lane per operand, fp32 accumulators, 2.5 PFLOP/s dense).
+//
+// This is the convolution of the Stable-Diffusion U-Net in its bf16 configuration (BASELINE.json configs[4]; reference
+// modules SD/ldm/modules/diffusionmodules/openaimodel.py:80-140 Upsample/Downsample, :163-275 ResBlock,
+// SD/ldm/modules/attention.py:218-260 proj_in/proj_out).  Round 1 ran that configuration on library kernels.
+//
+// Layout (MI355X-first, not the reference's): activations are NHWC bf16 — `[pixel][channel]`, the GEMM's natural
+// operand: a pixel's channels are one contiguous run, so the im2col gather is a 16-byte copy per (pixel, tap, 8
+// channels) and the transformer blocks' `b (h w) c` token view is the same memory.  Master weights stay fp32 OIHW in
+// the flat arena (the unit the saliency ranking and the masked update see); `salun_conv2d_bf16_pack_weights` writes the
+// bf16 image `[k][tap][c]` the kernels read (once per optimizer step).
+//
+//   forward        D[pixel][k] = sum_{tap,c} X[pixel+tap][c] * Wp[k][tap][c]       A = pixels (rows), B = weights
+//   backward-data  D[pixel][c] = sum_{tap,k} dY[pixel-tap][k] * Wp[k][tap][c]      same kernel; the B tile is staged
+//                  as [k][c] rows (contiguous in Wp) and read TRANSPOSED by ds_read_b64_tr_b16, so no second weight
+//                  image exists; a stride-2 convolution walks the zero-upsampled dY (taps on odd positions read 0)
+//   backward-weight dW[k][tap][c] = sum_pixel dY[pixel][k] * X[pixel+tap][c]       reduction over pixels: both operands
+//                  are needed pixel-major per lane, i.e. transposed — both tiles sit in LDS as they are in memory
+//                  ([pixel][32 channels], 64-byte rows = conflict-free for the transposing read) and every tap is an
+//                  immediate offset into the same input patch: 9 accumulators per wave, one staged patch per 64 pixels.
+//                  Pixel ranges are split over workgroups -> fp32 partials -> fixed-order reduce into OIHW (no atomics).
+//
+// Workgroup = 256 threads = 4 waves, each wave a 64x64 result tile (2x2 MFMA tiles, 64 fp32 accumulators); LDS double
+// buffered, global loads of stage i+1 in flight under the MFMAs of stage i, one barrier per stage.
+#include "salun_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+// round-to-nearest-even, NaN -> quiet NaN (what torch's float -> bfloat16 does)
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// 8 bf16 (one MFMA operand) = two transposing reads of 4: lane i of a 16-lane group receives column i of the
+// [4 rows][16 columns] block its group addresses (probe: tools/micro/bf16_probe.hip); `second` is the byte distance
+// of rows +4.
+__device__ __forceinline__ bf16x8 tr_operand(const char *lds_base, uint32_t byte_off, int second) {
+  lds_s16x4_ptr p0 = (lds_s16x4_ptr)(lds_base + byte_off);
+  lds_s16x4_ptr p1 = (lds_s16x4_ptr)(lds_base + byte_off + second);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p1);
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+// ------------------------------------------------------------------------------------------------ pack
+// fp32 OIHW [K][C][RS] -> bf16 [K][RS][C]; one thread writes 8 consecutive channels (16 B).
+__global__ __launch_bounds__(256) void k_pack_w(const float *__restrict__ w, uint16_t *__restrict__ wp, int K, int C,
+                                                int RS) {
+  const int c8n = C >> 3;
+  const int64_t total = (int64_t)K * RS * c8n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % c8n);
+    const int64_t kr = i / c8n;
+    const int rs = (int)(kr % RS);
+    const int64_t k = kr / RS;
+    const float *src = w + (k * C + (int64_t)c8 * 8) * RS + rs;
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = (uint32_t)f2bf(src[(2 * j) * RS]) | ((uint32_t)f2bf(src[(2 * j + 1) * RS]) << 16);
+    *reinterpret_cast<uint4 *>(wp + (kr * C + (int64_t)c8 * 8)) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// --------------------------------------------------------------------------------------- forward / backward-data
+struct IgArgs {
+  const uint16_t *x;       // [N][H][W][Cin] bf16 (forward: input; backward-data: dY)
+  const uint16_t *wp;      // packed weights [Kf][RS][Cf] bf16 (Kf, Cf = the FORWARD convolution's out / in channels)
+  const float *bias;       // [Kout] fp32 or null
+  const float *nbias;      // [N][Kout] fp32 or null (per-image channel offset: the time-embedding term of a ResBlock)
+  const uint16_t *addend;  // [M][Kout] bf16 or null (residual branch)
+  uint16_t *y;             // [M][Kout] bf16
+  int M;                   // output pixels N*OH*OW
+  int H, W, Cin;           // extent and channels of x
+  int OH, OW, Kout;        // extent and channels of y
+  int R, stride, pad, up;  // walk: virtual row = oh*stride - pad + r; `up` = 2 reads the zero-upsampled x (stride-2 dgrad)
+  int Kf, Cf;              // forward dims of the packed weights
+  float *part;             // split reduction: fp32 partial tiles [split][M][Kout] (null when gridDim.z == 1)
+  int stages_per_split;    // reduction stages (tap x channel chunk) per blockIdx.z
+};
+
+template <int WM, int WN, int BK, bool BTR>
+__global__ __launch_bounds__(256) void conv_bf16_igemm(const IgArgs g) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int CPR = BK / 8;                 // 16-byte chunks per A row
+  constexpr int ROWB = BK * 2 + 16;           // padded LDS row (conflict-free ds_read_b128 across 16 rows)
+  constexpr int NA = BM * CPR / 256;          // A chunks per thread per stage
+  constexpr int A_BYTES = BM * ROWB;
+  constexpr int B_BYTES = BTR ? (BN / 32) * (BK * 64) : BN * ROWB;
+  constexpr int NB = BTR ? (BK * BN / 8) / 256 : BN * CPR / 256;
+  static_assert(WM * WN == 4 && NA >= 1 && NB >= 1, "tile");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // buffer b: A at b*STAGE_BYTES, B behind it
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int RS = g.R * g.R;
+  const int cchunks = g.Cin / BK;
+  const int nstage_all = RS * cchunks;
+  const int st_begin = blockIdx.z * g.stages_per_split;
+  const int st_end = min(nstage_all, st_begin + g.stages_per_split);
+
+  // ---- the A rows this thread stages (fixed for the kernel)
+  const int a_cc = tid % CPR;
+  int a_hb[NA], a_wb[NA], a_nb[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = tid / CPR + (256 / CPR) * i;
+    const int m = m0 + row;
+    if (m < g.M) {
+      const int n = m / (g.OH * g.OW);
+      const int rem = m - n * (g.OH * g.OW);
+      const int oh = rem / g.OW, ow = rem - oh * g.OW;
+      a_hb[i] = oh * g.stride - g.pad;
+      a_wb[i] = ow * g.stride - g.pad;
+      a_nb[i] = n * g.H * g.W;
+    } else {
+      a_hb[i] = -(1 << 20); a_wb[i] = 0; a_nb[i] = 0;  // never in range
+    }
+  }
+  uint4 ra[NA], rb[NB];
+  auto load_stage = [&](int st) {
+    const int tap = st / cchunks, c0 = (st - tap * cchunks) * BK;
+    const int r = tap / g.R, s = tap - r * g.R;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int vh = a_hb[i] + r, vw = a_wb[i] + s;
+      bool ok = true;
+      if (g.up == 2) { ok = !((vh | vw) & 1); vh >>= 1; vw >>= 1; }
+      ok = ok && vh >= 0 && vh < g.H && vw >= 0 && vw < g.W;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (ok) ra[i] = *reinterpret_cast<const uint4 *>(g.x + ((size_t)(a_nb[i] + vh * g.W + vw) * g.Cin + c0 + a_cc * 8));
+    }
+    if (!BTR) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int row = tid / CPR + (256 / CPR) * i;
+        const int k = n0 + row;
+        rb[i] = make_uint4(0, 0, 0, 0);
+        if (k < g.Kout) rb[i] = *reinterpret_cast<const uint4 *>(g.wp + (((size_t)k * RS + tap) * g.Cin + c0 + a_cc * 8));
+      }
+    } else {
+      // backward-data: reduction row = forward out channel kf = c0 + row, flipped tap, columns = forward in channels
+      constexpr int CPB = BN / 8;  // chunks per reduction row
+      const int tapf = RS - 1 - tap;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id / CPB, cc = id - row * CPB;
+        const int col = n0 + cc * 8;
+        rb[i] = make_uint4(0, 0, 0, 0);
+        if (col < g.Kout) rb[i] = *reinterpret_cast<const uint4 *>(g.wp + (((size_t)(c0 + row) * RS + tapf) * g.Cf + col));
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = tid / CPR + (256 / CPR) * i;
+      *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + row * ROWB + a_cc * 16) = ra[i];
+    }
+    if (!BTR) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int row = tid / CPR + (256 / CPR) * i;
+        *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + row * ROWB + a_cc * 16) = rb[i];
+      }
+    } else {
+      constexpr int CPB = BN / 8;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id / CPB, cc = id - row * CPB;
+        *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + (cc >> 2) * (BK * 64) + row * 64 + (cc & 3) * 16) = rb[i];
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  const int a_off = (wm * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  const int b_off = (wn * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  // transposing read: 16-lane group gq, lane s: reduction row 8*(gq>>1) + (s>>2), columns 16*(gq&1) + 4*(s&3)
+  const int gq = lane >> 4, sl = lane & 15;
+  const uint32_t btr_off = (uint32_t)((wn * 2) * (BK * 64) + (8 * (gq >> 1) + (sl >> 2)) * 64 + (16 * (gq & 1) + 4 * (sl & 3)) * 2);
+
+  load_stage(st_begin);
+  store_stage(0);
+  __syncthreads();
+  for (int st = st_begin; st < st_end; ++st) {
+    const int buf = (st - st_begin) & 1;
+    if (st + 1 < st_end) load_stage(st + 1);
+    const char *A = lds + buf * STAGE_BYTES, *B = A + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(A + a_off + kk * 32);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(A + a_off + 32 * ROWB + kk * 32);
+      bf16x8 b0, b1;
+      if (!BTR) {
+        b0 = *reinterpret_cast<const bf16x8 *>(B + b_off + kk * 32);
+        b1 = *reinterpret_cast<const bf16x8 *>(B + b_off + 32 * ROWB + kk * 32);
+      } else {
+        b0 = tr_operand(B, btr_off + kk * (16 * 64), 4 * 64);
+        b1 = tr_operand(B, btr_off + BK * 64 + kk * (16 * 64), 4 * 64);
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (st + 1 < st_end) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+  if (g.part) {  // split reduction: raw fp32 tile, finished by k_splitk_finish
+    float *dst = g.part + (size_t)blockIdx.z * g.M * g.Kout;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (k >= g.Kout) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+          if (m < g.M) dst[(size_t)m * g.Kout + k] = acc[i][j][v];
+        }
+    }
+    return;
+  }
+
+  // ---- epilogue: D[row = pixel][col = channel]; row = (v&3) + 8*(v>>2) + 4*(lane>>5), col = lane&31
+  const int ohow = g.OH * g.OW;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = n0 + wn * 64 + j * 32 + (lane & 31);
+    if (k >= g.Kout) continue;
+    const float bk = g.bias ? g.bias[k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (m < g.M) {
+          float o = acc[i][j][v] + bk;
+          if (g.nbias) o += g.nbias[(size_t)(m / ohow) * g.Kout + k];
+          if (g.addend) o += bf2f(g.addend[(size_t)m * g.Kout + k]);
+          g.y[(size_t)m * g.Kout + k] = f2bf(o);
+        }
+      }
+    }
+  }
+}
+
+// out[m][k] = bf16( sum_z part[z][m][k] + bias[k] + nbias[n][k] + addend[m][k] ), 8 channels per thread
+__global__ __launch_bounds__(256) void k_splitk_finish(const float *__restrict__ part, int splits, const float *__restrict__ bias,
+                                                       const float *__restrict__ nbias, const uint16_t *__restrict__ addend,
+                                                       uint16_t *__restrict__ y, int M, int K, int ohow) {
+  const int k8n = K >> 3;
+  const int64_t total = (int64_t)M * k8n;
+  const int64_t mk = (int64_t)M * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / k8n), k = (int)(i - (int64_t)m * k8n) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int z = 0; z < splits; ++z) {
+      const float4 a = *reinterpret_cast<const float4 *>(part + z * mk + (int64_t)m * K + k);
+      const float4 b = *reinterpret_cast<const float4 *>(part + z * mk + (int64_t)m * K + k + 4);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (bias)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bias[k + j];
+    if (nbias)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += nbias[(size_t)(m / ohow) * K + k + j];
+    if (addend) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(addend + (int64_t)m * K + k);
+      const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f((uint16_t)(w[j] & 0xffffu)); v[2 * j + 1] += bf2f((uint16_t)(w[j] >> 16)); }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+    *reinterpret_cast<uint4 *>(y + (int64_t)m * K + k) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- backward-weight
+struct WgArgs {
+  const uint16_t *x;   // [N][H][W][C] bf16
+  const uint16_t *dy;  // [N][OH][OW][K] bf16
+  float *part;         // [split][RS][K][C] fp32 partial sums
+  int N, H, W, C, OH, OW, K, pad;
+  int tiles_h, tiles_w;       // 8x8 output-pixel chunks per image
+  int chunks, per_split;      // total chunks, chunks per split
+};
+
+// R: filter size (1 or 3); ST: convolution stride (1 or 2).  Workgroup tile = 64 k x 64 c x all R*R taps; wave (wk, wc)
+// owns 32 k x 32 c.  One stage = one 8x8 block of output pixels: dY rows [64 px][64 k] and the input patch
+// [(7*ST+R)^2 px][64 c], both as two [px][32 ch] column blocks with 64-byte rows.
+template <int R, int ST>
+__global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
+  constexpr int RS = R * R;
+  constexpr int PW = 7 * ST + R;               // patch width = height
+  constexpr int PPX = PW * PW;
+  constexpr int DY_BLK = 64 * 64;              // bytes of one [64 px][32 k] block
+  constexpr int X_BLK = PPX * 64;
+  constexpr int STAGE = 2 * DY_BLK + 2 * X_BLK;
+  constexpr int NDY = 2;                       // 512 chunks / 256 threads
+  constexpr int NX = (PPX * 8 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave & 1, wc = wave >> 1;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, split = blockIdx.z;
+  const int cb = split * g.per_split;
+  const int ce = min(g.chunks, cb + g.per_split);
+
+  uint4 rdy[NDY], rx[NX];
+  auto load_stage = [&](int chunk) {
+    const int per_img = g.tiles_h * g.tiles_w;
+    const int n = chunk / per_img;
+    const int t = chunk - n * per_img;
+    const int oh0 = (t / g.tiles_w) * 8, ow0 = (t % g.tiles_w) * 8;
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int id = tid + 256 * i;
+      const int px = id >> 3, cc = id & 7;
+      const int oh = oh0 + (px >> 3), ow = ow0 + (px & 7);
+      const int k = k0 + cc * 8;
+      rdy[i] = make_uint4(0, 0, 0, 0);
+      if (oh < g.OH && ow < g.OW && k < g.K)
+        rdy[i] = *reinterpret_cast<const uint4 *>(g.dy + ((size_t)((n * g.OH + oh) * g.OW + ow) * g.K + k));
+    }
+    const int ih0 = oh0 * ST - g.pad, iw0 = ow0 * ST - g.pad;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int id = tid + 256 * i;
+      const int px = id >> 3, cc = id & 7;
+      const int ih = ih0 + px / PW, iw = iw0 + px % PW;
+      const int c = c0 + cc * 8;
+      rx[i] = make_uint4(0, 0, 0, 0);
+      if (px < PPX && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && c < g.C)
+        rx[i] = *reinterpret_cast<const uint4 *>(g.x + ((size_t)((n * g.H + ih) * g.W + iw) * g.C + c));
+    }
+  };
+  auto store_stage = [&](int buf) {
+    char *base = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+      const int id = tid + 256 * i;
+      const int px = id >> 3, cc = id & 7;
+      *reinterpret_cast<uint4 *>(base + (cc >> 2) * DY_BLK + px * 64 + (cc & 3) * 16) = rdy[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int id = tid + 256 * i;
+      const int px = id >> 3, cc = id & 7;
+      if (px < PPX) *reinterpret_cast<uint4 *>(base + 2 * DY_BLK + (cc >> 2) * X_BLK + px * 64 + (cc & 3) * 16) = rx[i];
+    }
+  };
+
+  f32x16 acc[RS];
+#pragma unroll
+  for (int t = 0; t < RS; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  // transposing reads: group gq, lane s -> reduction pixel 8*(gq>>1) + (s>>2) (+4), channels 16*(gq&1) + 4*(s&3)
+  const int gq = lane >> 4, sl = lane & 15;
+  const int chan_b = (16 * (gq & 1) + 4 * (sl & 3)) * 2;
+  // k-step kk covers output pixels 16*kk .. 16*kk+15 = rows 2*kk, 2*kk+1 of the 8x8 block; this lane's pixel:
+  // row 2*kk + (gq>>1), column (s>>2) and (s>>2)+4
+  const uint32_t dy_off = (uint32_t)(wk * DY_BLK + (8 * (gq >> 1) + (sl >> 2)) * 64 + chan_b);
+  const uint32_t x_off = (uint32_t)(2 * DY_BLK + wc * X_BLK + (((gq >> 1) * ST) * PW + (sl >> 2) * ST) * 64 + chan_b);
+
+  if (cb < ce) {
+    load_stage(cb);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int ch = cb; ch < ce; ++ch) {
+    const int buf = (ch - cb) & 1;
+    if (ch + 1 < ce) load_stage(ch + 1);
+    const char *base = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 a = tr_operand(base, dy_off + kk * (16 * 64), 4 * 64);
+#pragma unroll
+      for (int t = 0; t < RS; ++t) {
+        const int r = t / R, s = t % R;
+        const bf16x8 b = tr_operand(base, x_off + (kk * 2 * ST * PW + r * PW + s) * 64, 4 * ST * 64);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < ce) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- partials: part[split][tap][k][c]; D row = k, col = c
+  const int c = c0 + wc * 32 + (lane & 31);
+  if (c < g.C) {
+#pragma unroll
+    for (int t = 0; t < RS; ++t) {
+      float *dst = g.part + (((size_t)split * RS + t) * g.K) * g.C;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = k0 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (k < g.K) dst[(size_t)k * g.C + c] = acc[t][v];
+      }
+    }
+  }
+}
+
+// part[split][RS][K][C] -> dw[K][C][RS] (OIHW), summed over splits in index order; thread = one (k, c), all taps
+__global__ __launch_bounds__(256) void k_wgrad_reduce_bf16(const float *__restrict__ part, float *__restrict__ dw, int K,
+                                                           int C, int RS, int splits, int accumulate) {
+  const int64_t kc = (int64_t)K * C;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= kc) return;
+  for (int t = 0; t < RS; ++t) {
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += part[((int64_t)sp * RS + t) * kc + i];
+    float *d = dw + i * RS + t;
+    *d = accumulate ? (*d + s) : s;
+  }
+}
+
+// per-channel sum over pixels of an NHWC bf16 tensor (the bias gradient): [M][K] -> fp32 [K]
+__global__ __launch_bounds__(256) void k_colsum_bf16(const uint16_t *__restrict__ dy, float *__restrict__ out, int64_t M,
+                                                     int K, int accumulate) {
+  // block = 32 channels x 8 row lanes; deterministic tree
+  __shared__ float s[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + cx;
+  float a = 0.f;
+  if (k < K)
+    for (int64_t m = ry; m < M; m += 8) a += bf2f(dy[m * K + k]);
+  s[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && k < K) {
+    float t = ((s[0][cx] + s[1][cx]) + (s[2][cx] + s[3][cx])) + ((s[4][cx] + s[5][cx]) + (s[6][cx] + s[7][cx]));
+    out[k] = accumulate ? out[k] + t : t;
+  }
+}
+
+int wgrad_splits(int tiles, int chunks) {
+  // about two resident rounds of workgroups (LDS admits 2-3 per CU), never more splits than chunks
+  int s = (768 + tiles - 1) / tiles;
+  if (s > chunks) s = chunks;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}
+
+bool supported(int C, int K, int R, int stride, int pad) {
+  return (R == 1 || R == 3) && (stride == 1 || stride == 2) && pad >= 0 && pad <= R - 1 && C % 32 == 0 && K % 32 == 0 &&
+         C >= 32 && K >= 32;
+}
+
+// Reduction split of the data kernels: a convolution with few output tiles (the 16x16 and 8x8 levels of the U-Net)
+// leaves most CUs without a workgroup, and a lone workgroup pays the full memory latency on every stage; splitting
+// the (tap, channel) reduction over blockIdx.z fills the chip (target: 3 workgroups per CU) at the price of one fp32
+// round trip of the output tile.
+struct SplitPlan { int splits, per; };
+SplitPlan plan_split(int tiles, int nstage) {
+  int s = 768 / (tiles < 1 ? 1 : tiles);
+  if (s > nstage / 6) s = nstage / 6;  // at least 6 stages per workgroup
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  const int per = (nstage + s - 1) / s;
+  s = (nstage + per - 1) / per;
+  return {s, per};
+}
+
+template <int WM, int WN, int BK, bool BTR>
+int launch_igemm(IgArgs a, void *ws, size_t ws_bytes, hipStream_t st) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int ROWB = BK * 2 + 16;
+  constexpr int A_BYTES = BM * ROWB;
+  constexpr int B_BYTES = BTR ? (BN / 32) * (BK * 64) : BN * ROWB;
+  const size_t lds = 2 * (size_t)(A_BYTES + B_BYTES);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_igemm<WM, WN, BK, BTR>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SALUN_EIO;
+    attr_done = true;
+  }
+  const int mt = (a.M + BM - 1) / BM, nt = (a.Kout + BN - 1) / BN;
+  const int nstage = a.R * a.R * (a.Cin / BK);
+  SplitPlan sp = plan_split(mt * nt, nstage);
+  if (sp.splits > 1 && (!ws || ws_bytes < (size_t)sp.splits * a.M * a.Kout * sizeof(float))) sp = {1, nstage};
+  a.stages_per_split = sp.per;
+  a.part = sp.splits > 1 ? static_cast<float *>(ws) : nullptr;
+  hipLaunchKernelGGL((conv_bf16_igemm<WM, WN, BK, BTR>), dim3(mt, nt, sp.splits), dim3(256), lds, st, a);
+  SALUN_LAUNCH_CHECK();
+  if (sp.splits > 1) {
+    const int64_t total = (int64_t)a.M * (a.Kout / 8);
+    hipLaunchKernelGGL(k_splitk_finish, dim3(salun_grid_for(total, 256)), dim3(256), 0, st, a.part, sp.splits, a.bias, a.nbias,
+                       a.addend, a.y, a.M, a.Kout, a.OH * a.OW);
+    SALUN_LAUNCH_CHECK();
+  }
+  return SALUN_OK;
+}
+
+#ifndef SALUN_BF16_TILE
+#define SALUN_BF16_TILE 0  // lab builds (tools/_run_bf16_lab.sh) pin one tile shape; 0 = choose per problem
+#endif
+
+template <bool BTR>
+int dispatch_igemm(const IgArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
+  const int bk64 = (a.Cin % 64 == 0);
+  if (SALUN_BF16_TILE == 1 && bk64) return launch_igemm<2, 2, 64, BTR>(a, ws, ws_bytes, st);
+  if (SALUN_BF16_TILE == 2) return launch_igemm<2, 2, 32, BTR>(a, ws, ws_bytes, st);
+  if (SALUN_BF16_TILE == 3 && bk64) return launch_igemm<4, 1, 64, BTR>(a, ws, ws_bytes, st);
+  if (SALUN_BF16_TILE == 4) return launch_igemm<4, 1, 32, BTR>(a, ws, ws_bytes, st);
+  return launch_igemm<2, 2, 32, BTR>(a, ws, ws_bytes, st);
+}
+
+template <int R, int ST>
+int launch_wgrad(const WgArgs &a, int splits, hipStream_t st) {
+  constexpr int PW = 7 * ST + R;
+  const size_t lds = 2 * (size_t)(2 * 64 * 64 + 2 * PW * PW * 64);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_wgrad<R, ST>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SALUN_EIO;
+    attr_done = true;
+  }
+  dim3 grid((a.K + 63) / 64, (a.C + 63) / 64, splits);
+  hipLaunchKernelGGL((conv_bf16_wgrad<R, ST>), grid, dim3(256), lds, st, a);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+}  // namespace
+
+// ================================================================== C-ABI =======
+SALUN_EXPORT int salun_conv2d_bf16_supported(int C, int K, int R, int stride, int pad) {
+  return supported(C, K, R, stride, pad) ? 1 : 0;
+}
+
+SALUN_EXPORT int salun_conv2d_bf16_pack_weights(const float *w, uint16_t *wp, int K, int C, int R, salun_stream_t stream) {
+  if (!w || !wp || K < 1 || C < 8 || C % 8 || (R != 1 && R != 3)) return SALUN_EINVAL;
+  if (!salun_aligned16(wp)) return SALUN_EINVAL;
+  const int64_t total = (int64_t)K * R * R * (C / 8);
+  hipLaunchKernelGGL(k_pack_w, dim3(salun_grid_for(total, 256)), dim3(256), 0, salun_hip_stream(stream), w, wp, K, C, R * R);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+// Scratch for the reduction split of forward / backward-data: 16 fp32 copies of the larger of the two outputs is the
+// most any plan uses; a smaller (or null) workspace only disables the split.
+SALUN_EXPORT size_t salun_conv2d_bf16_data_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad) {
+  if (!supported(C, K, R, stride, pad) || N < 1 || H < 1 || W < 1) return 0;
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+  const int BK = 32;
+  size_t need = 0;
+  {  // forward
+    const int M = N * OH * OW, tiles = ((M + 127) / 128) * ((K + 127) / 128);
+    const SplitPlan sp = plan_split(tiles, R * R * (C / BK));
+    if (sp.splits > 1) need = (size_t)sp.splits * M * K * sizeof(float);
+  }
+  {  // backward-data
+    const int M = N * H * W, tiles = ((M + 127) / 128) * ((C + 127) / 128);
+    const SplitPlan sp = plan_split(tiles, R * R * (K / BK));
+    const size_t b = sp.splits > 1 ? (size_t)sp.splits * M * C * sizeof(float) : 0;
+    if (b > need) need = b;
+  }
+  return need;
+}
+
+SALUN_EXPORT int salun_conv2d_bf16_forward(const uint16_t *x, const uint16_t *wp, const float *bias, const float *nbias,
+                                           const uint16_t *addend, uint16_t *y, int N, int H, int W, int C, int K, int R,
+                                           int stride, int pad, void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (!x || !wp || !y || N < 1 || H < 1 || W < 1 || !supported(C, K, R, stride, pad)) return SALUN_EINVAL;
+  if (!salun_aligned16(x) || !salun_aligned16(wp)) return SALUN_EINVAL;
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+  if (OH < 1 || OW < 1 || (int64_t)N * H * W * C >= (int64_t(1) << 31) || (int64_t)N * OH * OW * K >= (int64_t(1) << 31))
+    return SALUN_EINVAL;
+  IgArgs a{x, wp, bias, nbias, addend, y, N * OH * OW, H, W, C, OH, OW, K, R, stride, pad, 1, K, C, nullptr, 0};
+  return dispatch_igemm<false>(a, ws, ws_bytes, salun_hip_stream(stream));
+}
+
+// dx[N][H][W][C] from dy[N][OH][OW][K]; `addend` (same shape as dx, may be null) rides in the epilogue.
+SALUN_EXPORT int salun_conv2d_bf16_backward_data(const uint16_t *dy, const uint16_t *wp, const uint16_t *addend,
+                                                 uint16_t *dx, int N, int H, int W, int C, int K, int R, int stride,
+                                                 int pad, void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (!dy || !wp || !dx || N < 1 || H < 1 || W < 1 || !supported(C, K, R, stride, pad)) return SALUN_EINVAL;
+  if (!salun_aligned16(dy) || !salun_aligned16(wp)) return SALUN_EINVAL;
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+  if (OH < 1 || OW < 1 || (int64_t)N * H * W * C >= (int64_t(1) << 31) || (int64_t)N * OH * OW * K >= (int64_t(1) << 31))
+    return SALUN_EINVAL;
+  // walk dX's pixels; the source is dY (zero-upsampled by `stride`), padding R-1-pad, taps flipped in the weight read
+  IgArgs a{dy, wp, nullptr, nullptr, addend, dx, N * H * W, OH, OW, K, H, W, C, R, 1, R - 1 - pad, stride, K, C, nullptr, 0};
+  return dispatch_igemm<true>(a, ws, ws_bytes, salun_hip_stream(stream));
+}
+
+SALUN_EXPORT size_t salun_conv2d_bf16_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad) {
+  if (!supported(C, K, R, stride, pad) || N < 1) return 0;
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+  const int chunks = N * ((OH + 7) / 8) * ((OW + 7) / 8);
+  const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
+  return (size_t)wgrad_splits(tiles, chunks) * R * R * K * C * sizeof(float);
+}
+
+// dw fp32 OIHW [K][C][R][R] (+= when accumulate); db fp32 [K] or null (the bias gradient, += when accumulate)
+SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N,
+                                                   int H, int W, int C, int K, int R, int stride, int pad, int accumulate,
+                                                   void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (!x || !dy || !dw || !ws || N < 1 || !supported(C, K, R, stride, pad)) return SALUN_EINVAL;
+  if (!salun_aligned16(x) || !salun_aligned16(dy)) return SALUN_EINVAL;
+  const size_t need = salun_conv2d_bf16_wgrad_workspace_bytes(N, H, W, C, K, R, stride, pad);
+  if (ws_bytes < need) return SALUN_ENOSPC;
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+  WgArgs a;
+  a.x = x; a.dy = dy; a.part = static_cast<float *>(ws);
+  a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.pad = pad;
+  a.tiles_h = (OH + 7) / 8; a.tiles_w = (OW + 7) / 8;
+  a.chunks = N * a.tiles_h * a.tiles_w;
+  const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
+  const int splits = wgrad_splits(tiles, a.chunks);
+  a.per_split = (a.chunks + splits - 1) / splits;
+  hipStream_t st = salun_hip_stream(stream);
+  int rc;
+  if (R == 3 && stride == 1) rc = launch_wgrad<3, 1>(a, splits, st);
+  else if (R == 3) rc = launch_wgrad<3, 2>(a, splits, st);
+  else if (stride == 1) rc = launch_wgrad<1, 1>(a, splits, st);
+  else rc = launch_wgrad<1, 2>(a, splits, st);
+  if (rc != SALUN_OK) return rc;
+  const int64_t kc = (int64_t)K * C;
+  hipLaunchKernelGGL(k_wgrad_reduce_bf16, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, st, a.part, dw, K, C, R * R,
+                     splits, accumulate);
+  SALUN_LAUNCH_CHECK();
+  if (db) {
+    hipLaunchKernelGGL(k_colsum_bf16, dim3((K + 31) / 32), dim3(256), 0, st, dy, db, (int64_t)N * OH * OW, K, accumulate);
+    SALUN_LAUNCH_CHECK();
+  }
+  return SALUN_OK;
+}

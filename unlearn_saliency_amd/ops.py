@@ -288,6 +288,74 @@ def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: i
     return dw
 
 
+# ----------------------------------------------------------------------------- K11
+# bf16 NHWC convolution on the bf16 matrix-core instruction; tensors are [N, H, W, C] contiguous bfloat16.
+def conv2d_bf16_supported(C: int, K: int, R: int, stride: int, pad: int) -> bool:
+    return bool(_lib.lib().salun_conv2d_bf16_supported(C, K, R, stride, pad))
+
+
+def conv2d_bf16_pack(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 OIHW master weights -> the bf16 image [K, R*R, C] the forward and backward-data kernels read."""
+    K, C, R, _ = w.shape
+    if out is None:
+        out = torch.empty((K, R * R, C), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().salun_conv2d_bf16_pack_weights(_dev(w, torch.float32, "w"), _dev(out, torch.bfloat16, "wp"), K, C, R,
+                                                    _stream()), "salun_conv2d_bf16_pack_weights")
+    return out
+
+
+def conv2d_bf16_forward(x: torch.Tensor, wp: torch.Tensor, R: int, stride: int, pad: int,
+                        bias: Optional[torch.Tensor] = None, nbias: Optional[torch.Tensor] = None,
+                        addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    N, H, W, C = x.shape
+    K = wp.shape[0]
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    y = torch.empty((N, OH, OW, K), dtype=torch.bfloat16, device=x.device)
+    ws = workspace(_lib.lib().salun_conv2d_bf16_data_workspace_bytes(N, H, W, C, K, R, stride, pad), x.device)
+    check(_lib.lib().salun_conv2d_bf16_forward(_dev(x, torch.bfloat16, "x"), _dev(wp, torch.bfloat16, "wp"),
+                                               _dev(bias, torch.float32, "bias", True),
+                                               _dev(nbias, torch.float32, "nbias", True),
+                                               _dev(addend, torch.bfloat16, "addend", True), c_void_p(y.data_ptr()),
+                                               N, H, W, C, K, R, stride, pad, c_void_p(ws.data_ptr()),
+                                               c_size_t(ws.numel()), _stream()), "salun_conv2d_bf16_forward")
+    return y
+
+
+def conv2d_bf16_backward_data(dy: torch.Tensor, wp: torch.Tensor, x_shape, R: int, stride: int, pad: int,
+                              addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    N, H, W, C = x_shape
+    K = wp.shape[0]
+    dx = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
+    ws = workspace(_lib.lib().salun_conv2d_bf16_data_workspace_bytes(N, H, W, C, K, R, stride, pad), dy.device)
+    check(_lib.lib().salun_conv2d_bf16_backward_data(_dev(dy, torch.bfloat16, "dy"), _dev(wp, torch.bfloat16, "wp"),
+                                                     _dev(addend, torch.bfloat16, "addend", True),
+                                                     c_void_p(dx.data_ptr()), N, H, W, C, K, R, stride, pad,
+                                                     c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()),
+          "salun_conv2d_bf16_backward_data")
+    return dx
+
+
+def conv2d_bf16_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: int, pad: int,
+                                out: Optional[torch.Tensor] = None, accumulate: bool = False,
+                                bias_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dw fp32 OIHW (written, or added into `out` when accumulate); `bias_out` (fp32 [K]) receives / accumulates the
+    per-channel sum of dy in the same call."""
+    N, H, W, C = x.shape
+    K, _, R, _ = w_shape
+    L = _lib.lib()
+    nbytes = L.salun_conv2d_bf16_wgrad_workspace_bytes(N, H, W, C, K, R, stride, pad)
+    if nbytes == 0:
+        raise ValueError(f"bf16 backward-weight: unsupported shape C={C} K={K} R={R} stride={stride} pad={pad}")
+    ws = workspace(nbytes, x.device)
+    dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    check(L.salun_conv2d_bf16_backward_weight(_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"),
+                                              _dev(dw, torch.float32, "dw"), _dev(bias_out, torch.float32, "db", True),
+                                              N, H, W, C, K, R, stride, pad, int(bool(accumulate and out is not None)),
+                                              c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()),
+          "salun_conv2d_bf16_backward_weight")
+    return dw
+
+
 # ------------------------------------------------------------------- fused BatchNorm
 def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
                num_batches_tracked=None):

@@ -271,6 +271,25 @@ int salun_conv2d_bf16_backward_weight(const uint16_t *x /*dev*/, const uint16_t 
                                       int pad, int accumulate, void *ws /*dev*/, size_t ws_bytes,
                                       salun_stream_t stream);
 
+/* ------------------------------------------------------------------ K12 --
+ * GroupNorm (+ SiLU) on bf16 NHWC activations with fp32 statistics — the `GroupNorm32` layers of the SD U-Net in its
+ * bf16 configuration (SD/ldm/modules/diffusionmodules/util.py:215-217: `super().forward(x.float()).type(x.dtype)`,
+ * followed by nn.SiLU in openaimodel.py:192-196,214-221,716-718; attention.py:228 without SiLU).
+ *   forward : y = [silu]( gamma*(x-mean)*rstd + beta ), x / y [N][HW][C] bf16, C % 8 == 0, C % G == 0;
+ *             mr[N][G][2] = (mean, rstd) and ab[N][C][2] = (gamma*rstd, beta - mean*gamma*rstd) are outputs the
+ *             backward consumes (biased variance, as torch.nn.GroupNorm).
+ *   backward: dz = dy * silu'(z); dbeta = sum dz; dgamma = sum dz*xhat; dx = rstd*(dz*gamma - (s1 + xhat*s2)/m)
+ *             with s1 = sum_group dz*gamma, s2 = sum_group dz*gamma*xhat.  dgamma / dbeta fp32 (= or += if accumulate).
+ * Reductions: per-channel fp32 partials over pixel chunks, folded in fp64 in a fixed order (deterministic). */
+size_t salun_gn_bf16_workspace_bytes(int N, int C, int HW, int G);
+int salun_gn_bf16_forward(const uint16_t *x /*dev*/, const float *gamma /*dev*/, const float *beta /*dev*/,
+                          uint16_t *y /*dev*/, float *mr /*dev*/, float *ab /*dev*/, int N, int C, int HW, int G,
+                          double eps, int silu, void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+int salun_gn_bf16_backward(const uint16_t *dy /*dev*/, const uint16_t *x /*dev*/, const float *gamma /*dev*/,
+                           const float *mr /*dev*/, const float *ab /*dev*/, uint16_t *dx /*dev*/, float *dgamma /*dev*/,
+                           float *dbeta /*dev*/, int N, int C, int HW, int G, int silu, int accumulate, void *ws /*dev*/,
+                           size_t ws_bytes, salun_stream_t stream);
+
 /* Fused BatchNorm2d (+ residual add) (+ ReLU), NCHW fp32, forward and backward — replaces the
  * bn -> relu / bn -> (+identity) -> relu chains of the classifier blocks
  *   (Classification/models/ResNet.py:108-125,307-309) that run as separate library launches.

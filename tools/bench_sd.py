@@ -37,9 +37,12 @@ def main():
     arena = TS._unet_arena(model)
     assert arena.n == NS, arena.n
     n_salun = 0
+    from unlearn_saliency_amd import conv as sconv
     if not a.library_conv and not a.bf16:
-        from unlearn_saliency_amd.conv import use_salun_convs
-        n_salun = use_salun_convs(model)
+        n_salun = sconv.use_salun_convs(model)
+    elif not a.library_conv:
+        from unlearn_saliency_amd.conv_bf16 import use_salun_convs_bf16
+        n_salun = use_salun_convs_bf16(model)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0
     B = a.batch
@@ -109,7 +112,7 @@ def main():
         "metric": "sd_unlearn_steps_per_sec (SD-v1 U-Net nsfw_removal body, batch 8, 64x64 latents)",
         "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "steps": a.steps, "warmup": a.warmup,
         "dtype": "bf16 autocast (fp32 master weights / Adam)" if a.bf16 else "f32", "data": "synthetic",
-        "params": NS, "salun_mfma_convs": n_salun, "init_sec": t_init,
+        "params": NS, "salun_mfma_convs": n_salun, "library_conv_calls": sconv.library_conv_calls(), "init_sec": t_init,
         "mask_gen": {"batches": a.mask_batches, "saliency_sec": t_mask, "topk_ms_at_NS": topk_ms,
                      "topk_GBps_algorithmic": 5.0 * NS / (topk_ms * 1e-3) / 1e9},
         "roofline": {"kernel": "salun_masked_adam_step @ N_S", "bound": "hbm", "algorithmic_bytes": 29 * NS,

@@ -45,6 +45,15 @@ class LatentDiffusionLite(nn.Module):
     def device(self):
         return self.sqrt_alphas_cumprod.device
 
+    def use_mfma_convs(self) -> int:
+        """Put the U-Net's convolutions on this package's matrix-core kernels: bf16 NHWC (conv_bf16.py, K11) in the
+        bf16 configuration, fp32 NCHW (conv.py, K8) otherwise.  Returns the number of modules switched."""
+        if self.bf16:
+            from ..conv_bf16 import use_salun_convs_bf16
+            return use_salun_convs_bf16(self.model.diffusion_model)
+        from ..conv import use_salun_convs
+        return use_salun_convs(self.model.diffusion_model)
+
     # ---- the calls the scripts make
     def get_input(self, batch, k=None):
         """-> (z, c).  Accepts {"z","c"} (latents + context) or, with encoders attached, {"jpg","txt"}."""

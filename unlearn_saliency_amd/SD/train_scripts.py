@@ -46,6 +46,8 @@ def setup_model(config_path, ckpt_path, device, bf16=False) -> LatentDiffusionLi
         sd = sd.get("state_dict", sd)
         unet_sd = {k[len(UNET_PREFIX):]: v for k, v in sd.items() if k.startswith(UNET_PREFIX)}
         model.model.diffusion_model.load_state_dict(unet_sd, strict=True)
+    if torch.device(device).type == "cuda":
+        model.use_mfma_convs()
     return model
 
 

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint as _ckpt
 
+from ..conv_bf16 import SalunConv2dBF16
 from ..norm import _GN_TYPES, fused_gn_act
 
 
@@ -99,10 +100,16 @@ class ResBlock(nn.Module):
     def _forward(self, x, emb):
         # GroupNorm32 -> SiLU as one kernel (norm.fused_gn_act; falls back to the library ops under autocast / for
         # shapes outside the kernel's domain); the remaining layers of each Sequential run as they are
-        h = self.in_layers[2](fused_gn_act(x, self.in_layers[0], silu=True))
+        conv1, conv2 = self.in_layers[2], self.out_layers[3]
+        if isinstance(conv1, SalunConv2dBF16) and isinstance(conv2, SalunConv2dBF16):
+            # bf16 kernels: the time-embedding term and the residual branch ride in the convolutions' epilogues
+            h = conv1(fused_gn_act(x, self.in_layers[0], silu=True), nbias=self.emb_layers(emb).float())
+            o = fused_gn_act(h, self.out_layers[0], silu=True)
+            return conv2(self.out_layers[2](o), addend=self.skip_connection(x))
+        h = conv1(fused_gn_act(x, self.in_layers[0], silu=True))
         h = h + self.emb_layers(emb).type(h.dtype)[..., None, None]
         o = fused_gn_act(h, self.out_layers[0], silu=True)
-        return self.skip_connection(x) + self.out_layers[3](self.out_layers[2](o))
+        return self.skip_connection(x) + conv2(self.out_layers[2](o))
 
     def forward(self, x, emb):
         if self.use_checkpoint and torch.is_grad_enabled():
@@ -186,8 +193,10 @@ class SpatialTransformer(nn.Module):
         t = self.proj_in(fused_gn_act(x, self.norm, silu=False)).flatten(2).transpose(1, 2).contiguous()  # b (h w) c
         for blk in self.transformer_blocks:
             t = blk(t, context)
-        t = t.transpose(1, 2).reshape(b, -1, h, w).contiguous()
-        return self.proj_out(t) + x
+        t = t.transpose(1, 2).reshape(b, -1, h, w)  # channels_last view of the token tensor
+        if isinstance(self.proj_out, SalunConv2dBF16):  # NHWC kernels: no copy, the residual rides in the epilogue
+            return self.proj_out(t, addend=x)
+        return self.proj_out(t.contiguous()) + x
 
 
 class UNetModel(nn.Module):

@@ -1,0 +1,118 @@
+"""`nn.Conv2d` on the bf16 MFMA convolution kernels (csrc/salun_conv_bf16.hip, K11) — the convolution path of the
+Stable-Diffusion U-Net in its bf16 configuration (BASELINE.json configs[4]; reference: autocast over the `conv_nd`
+modules of SD/ldm/modules/diffusionmodules/openaimodel.py and SD/ldm/modules/attention.py:230-247).
+
+`use_salun_convs_bf16(model)` re-classes every eligible `nn.Conv2d` in place (parameters, names, state_dict untouched:
+the fp32 master weights stay views of the flat arena).  Such a module
+
+  * takes any 4-D device tensor, views it as bf16 NHWC (`channels_last` — a no-op for tensors these modules produced),
+  * reads a bf16 image of its weight that is re-packed only when the master weights changed (`ops.PARAM_EPOCH`, bumped
+    by the fused optimizer kernels, plus torch's own version counter),
+  * returns a bf16 `channels_last` tensor (logical NCHW shape, so the surrounding model code is unchanged),
+  * in backward writes dX in bf16 and adds dW / db in fp32 straight into the parameters' `.grad` views (gradsink.py).
+
+Shapes outside the kernels' domain (C or K not a multiple of 32: the 4-channel latent head and tail of the U-Net)
+run on the fp32 MFMA kernels of conv.py; nothing here calls the library convolution.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import gradsink, ops
+from .conv import SalunConv2d, _eligible
+
+
+def _nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW tensor -> contiguous [N, H, W, C] bf16 view/copy."""
+    return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+
+class _ConvBF16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, mod, nbias, addend):
+        R, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+        xn = _nhwc(x)
+        wp = mod.packed_weight()
+        an = _nhwc(addend) if addend is not None else None
+        y = ops.conv2d_bf16_forward(xn, wp, R, s, p, bias=bias, nbias=nbias, addend=an)
+        ctx.save_for_backward(xn, w)
+        ctx.mod, ctx.has_bias, ctx.x_dtype = mod, bias is not None, x.dtype
+        ctx.nbias, ctx.addend_dtype = nbias is not None, (addend.dtype if addend is not None else None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, w = ctx.saved_tensors
+        mod = ctx.mod
+        R, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+        dyn = _nhwc(dy)
+        dx = dw = db = dnb = dadd = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dst = gradsink.sink(w)
+            bdst = gradsink.sink(mod.bias) if ctx.has_bias else None
+            if ctx.has_bias and bdst is None:
+                bdst = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+                db = bdst
+            got = ops.conv2d_bf16_backward_weight(xn, dyn, tuple(w.shape), s, p, out=dst, accumulate=True, bias_out=bdst)
+            if dst is None:
+                dw = got
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_bf16_backward_data(dyn, mod.packed_weight(), tuple(xn.shape), R, s, p).permute(0, 3, 1, 2)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        if ctx.nbias and ctx.needs_input_grad[4]:
+            dnb = dyn.float().sum(dim=(1, 2))
+        if ctx.addend_dtype is not None and ctx.needs_input_grad[5]:
+            dadd = dy if dy.dtype == ctx.addend_dtype else dy.to(ctx.addend_dtype)
+        return dx, dw, db, None, dnb, dadd
+
+
+class SalunConv2dBF16(nn.Conv2d):
+    """Same parameters / state_dict as nn.Conv2d; device tensors go through the bf16 MFMA kernels."""
+
+    _pack = None
+    _pack_key = None
+
+    def packed_weight(self) -> torch.Tensor:
+        w = self.weight
+        key = (ops.PARAM_EPOCH[0], w._version, w.data_ptr())
+        if self._pack is None or self._pack_key != key or self._pack.device != w.device:
+            self._pack = ops.conv2d_bf16_pack(w.detach(), self._pack if self._pack is not None and self._pack.device == w.device else None)
+            self._pack_key = key
+        return self._pack
+
+    def forward(self, x, nbias=None, addend=None):
+        """`nbias` ([N, K] fp32, e.g. a ResBlock's time-embedding term) and `addend` (a tensor of the output's shape,
+        e.g. the residual branch) are added in the kernel's epilogue."""
+        if not x.is_cuda or x.dim() != 4:
+            raise RuntimeError("SalunConv2dBF16 needs a 4-D device tensor (the HIP kernels have no CPU path)")
+        return _ConvBF16Fn.apply(x, self.weight, self.bias, self, nbias, addend)
+
+
+class _Fp32Island(SalunConv2d):
+    """The two 4-channel convolutions of the U-Net (latent head / tail) inside a bf16 model: fp32 MFMA kernels on an
+    fp32 NCHW copy of the input; the result keeps fp32 (the head feeds GroupNorm, the tail is the model output)."""
+
+    def forward(self, x):
+        with torch.autocast("cuda", enabled=False):  # SalunConv2d refuses autocast regions; this island is fp32 by design
+            y = super().forward(x.float().contiguous())
+        if self.out_channels % 32 == 0:  # the head: its output feeds the bf16 NHWC network (and the skip concatenations)
+            y = y.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        return y
+
+
+def use_salun_convs_bf16(model: nn.Module) -> int:
+    """Re-class eligible nn.Conv2d modules in place; returns how many run on the bf16 kernels."""
+    n = 0
+    for mod in model.modules():
+        if type(mod) is not nn.Conv2d or not _eligible(mod):
+            continue
+        K, C = mod.out_channels, mod.in_channels
+        R, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+        if C % 32 == 0 and K % 32 == 0 and ops.conv2d_bf16_supported(C, K, R, s, p):
+            mod.__class__ = SalunConv2dBF16
+            n += 1
+        else:
+            mod.__class__ = _Fp32Island
+    return n

@@ -448,22 +448,44 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_bf16(const float *__restri
   }
 }
 
-// per-channel sum over pixels of an NHWC bf16 tensor (the bias gradient): [M][K] -> fp32 [K]
-__global__ __launch_bounds__(256) void k_colsum_bf16(const uint16_t *__restrict__ dy, float *__restrict__ out, int64_t M,
-                                                     int K, int accumulate) {
-  // block = 32 channels x 8 row lanes; deterministic tree
-  __shared__ float s[8][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + cx;
-  float a = 0.f;
+// per-channel sum over pixels of an NHWC bf16 tensor (the bias gradient): [M][K] -> fp32 [K], two deterministic stages.
+// Stage 1: block = 32 channel groups (8 channels each, one 16-byte load) x 8 row lanes over one row chunk.
+constexpr int COLSUM_CHUNKS = 128;
+__global__ __launch_bounds__(256) void k_colsum_partial(const uint16_t *__restrict__ dy, float *__restrict__ part, int64_t M,
+                                                        int K, int64_t rows_per_chunk) {
+  __shared__ float s[8][32][9];
+  const int gx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int k = (blockIdx.x * 32 + gx) * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
   if (k < K)
-    for (int64_t m = ry; m < M; m += 8) a += bf2f(dy[m * K + k]);
-  s[ry][cx] = a;
+    for (int64_t m = r0 + ry; m < r1; m += 8) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(dy + m * K + k);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[2 * j] += bf2f((uint16_t)(w[j] & 0xffffu)); a[2 * j + 1] += bf2f((uint16_t)(w[j] >> 16)); }
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[ry][gx][j] = a[j];
   __syncthreads();
   if (ry == 0 && k < K) {
-    float t = ((s[0][cx] + s[1][cx]) + (s[2][cx] + s[3][cx])) + ((s[4][cx] + s[5][cx]) + (s[6][cx] + s[7][cx]));
-    out[k] = accumulate ? out[k] + t : t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = ((s[0][gx][j] + s[1][gx][j]) + (s[2][gx][j] + s[3][gx][j])) + ((s[4][gx][j] + s[5][gx][j]) + (s[6][gx][j] + s[7][gx][j]));
+      part[(size_t)blockIdx.y * K + k + j] = t;
+    }
   }
+}
+__global__ __launch_bounds__(256) void k_colsum_finish(const float *__restrict__ part, float *__restrict__ out, int K, int chunks,
+                                                       int accumulate) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float t = 0.f;
+  for (int c = 0; c < chunks; ++c) t += part[(size_t)c * K + k];
+  out[k] = accumulate ? out[k] + t : t;
 }
 
 int wgrad_splits(int tiles, int chunks) {
@@ -625,7 +647,7 @@ SALUN_EXPORT size_t salun_conv2d_bf16_wgrad_workspace_bytes(int N, int H, int W,
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
   const int chunks = N * ((OH + 7) / 8) * ((OW + 7) / 8);
   const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
-  return (size_t)wgrad_splits(tiles, chunks) * R * R * K * C * sizeof(float);
+  return (size_t)wgrad_splits(tiles, chunks) * R * R * K * C * sizeof(float) + (size_t)COLSUM_CHUNKS * K * sizeof(float);
 }
 
 // dw fp32 OIHW [K][C][R][R] (+= when accumulate); db fp32 [K] or null (the bias gradient, += when accumulate)
@@ -657,7 +679,14 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
                      splits, accumulate);
   SALUN_LAUNCH_CHECK();
   if (db) {
-    hipLaunchKernelGGL(k_colsum_bf16, dim3((K + 31) / 32), dim3(256), 0, st, dy, db, (int64_t)N * OH * OW, K, accumulate);
+    const int64_t M = (int64_t)N * OH * OW;
+    int chunks = (int)((M + 63) / 64);
+    if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
+    const int64_t rpc = (M + chunks - 1) / chunks;
+    float *cpart = a.part + (size_t)splits * R * R * K * C;
+    hipLaunchKernelGGL(k_colsum_partial, dim3((K / 8 + 31) / 32, chunks), dim3(256), 0, st, dy, cpart, M, K, rpc);
+    SALUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_colsum_finish, dim3((K + 255) / 256), dim3(256), 0, st, cpart, db, K, chunks, accumulate);
     SALUN_LAUNCH_CHECK();
   }
   return SALUN_OK;

@@ -85,6 +85,31 @@ class _FusedGN(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None
 
 
+class _FusedGN16(torch.autograd.Function):
+    """GroupNorm (+ SiLU) of a bf16 activation on csrc/salun_norm_bf16.hip (K12): NHWC bf16 in / out, fp32 statistics.
+    The input may be any 4-D bf16 device tensor (logical NCHW); `channels_last` inputs are used as they are."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, silu):
+        xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        y, mr, ab = ops.gn_bf16_forward(xn, weight, bias, groups, eps, silu)
+        ctx.save_for_backward(xn, weight, bias, mr, ab)
+        ctx.cfg = (int(groups), bool(silu))
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, weight, bias, mr, ab = ctx.saved_tensors
+        groups, silu = ctx.cfg
+        dyn = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        gw, gb = gradsink.sink(weight), gradsink.sink(bias)
+        sunk = gw is not None and gb is not None
+        if not sunk:
+            gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+        dx = ops.gn_bf16_backward(dyn, xn, weight, mr, ab, groups, silu, gw, gb, accumulate=sunk)
+        return dx.permute(0, 3, 1, 2), (None if sunk else gw), (None if sunk else gb), None, None, None
+
+
 _FUSED_GN = True
 
 
@@ -98,6 +123,9 @@ def fused_gn_act(x: torch.Tensor, gn: nn.GroupNorm, silu: bool = True) -> torch.
     """`[x * sigmoid(x)](gn(x))` — one forward and two backward launches on csrc/salun_norm.hip for fp32 NCHW device
     tensors whose H*W is a power of two; anything else runs the library ops."""
     hw = x.shape[2] * x.shape[3] if x.dim() == 4 else 0
+    if (_FUSED_GN and type(gn) in _GN_TYPES and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and gn.affine
+            and x.shape[1] % 8 == 0 and gn.weight.dtype == torch.float32):
+        return _FusedGN16.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, silu)
     if (_FUSED_GN and type(gn) in _GN_TYPES and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and gn.affine and hw >= 4 and (hw & (hw - 1)) == 0 and x.shape[1] // gn.num_groups <= 256
             and not torch.is_autocast_enabled()):

@@ -51,6 +51,12 @@ def workspace(nbytes: int, device: torch.device, tag: str = "") -> torch.Tensor:
     return w
 
 
+# Bumped by every kernel that rewrites parameters through raw pointers (the fused optimizer steps, the proximal
+# step): torch's version counters do not see those writes, and derived images of the weights (the bf16 weight pack of
+# conv_bf16.py) are cached against this counter.
+PARAM_EPOCH = [0]
+
+
 # ----------------------------------------------------------------------------- K1
 def saliency_accumulate(acc: torch.Tensor, g: torch.Tensor, scale: float = 1.0,
                         sqnorm: Optional[torch.Tensor] = None, max_norm: float = 1.0) -> None:
@@ -137,6 +143,7 @@ def masked_sgd_step(p: torch.Tensor, g: torch.Tensor, buf: Optional[torch.Tensor
                     lr: float, momentum: float, weight_decay: float, first_step: bool) -> None:
     n = p.numel()
     assert g.numel() == n and (buf is None or buf.numel() == n) and (m is None or m.numel() == n)
+    PARAM_EPOCH[0] += 1
     check(_lib.lib().salun_masked_sgd_step(_dev(p, torch.float32, "p"), _dev(g, torch.float32, "g"),
                                            _dev(buf, torch.float32, "buf", True), _dev(m, torch.uint8, "mask", True),
                                            c_double(lr), c_double(momentum), c_double(weight_decay),
@@ -161,6 +168,7 @@ def masked_adam_step(p: torch.Tensor, g: torch.Tensor, m1: torch.Tensor, v: torc
                      max_norm: float = 1.0, gscale: float = 1.0) -> None:
     n = p.numel()
     assert g.numel() == n and m1.numel() == n and v.numel() == n and (mask is None or mask.numel() == n)
+    PARAM_EPOCH[0] += 1
     check(_lib.lib().salun_masked_adam_step(_dev(p, torch.float32, "p"), _dev(g, torch.float32, "g"),
                                             _dev(m1, torch.float32, "exp_avg"), _dev(v, torch.float32, "exp_avg_sq"),
                                             _dev(mask, torch.uint8, "mask", True),
@@ -356,6 +364,37 @@ def conv2d_bf16_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stri
     return dw
 
 
+# ----------------------------------------------------------------------------- K12
+def gn_bf16_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool):
+    """x [N, H, W, C] bf16 contiguous -> (y, mr, ab): y = [silu](GroupNorm(x)); mr / ab feed gn_bf16_backward."""
+    N, H, W, C = x.shape
+    L = _lib.lib()
+    ws = workspace(L.salun_gn_bf16_workspace_bytes(N, C, H * W, groups), x.device)
+    y = torch.empty_like(x)
+    mr = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
+    ab = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+    check(L.salun_gn_bf16_forward(_dev(x, torch.bfloat16, "x"), _dev(gamma, torch.float32, "gamma"),
+                                  _dev(beta, torch.float32, "beta"), c_void_p(y.data_ptr()), c_void_p(mr.data_ptr()),
+                                  c_void_p(ab.data_ptr()), N, C, H * W, groups, c_double(eps), int(bool(silu)),
+                                  c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()), "salun_gn_bf16_forward")
+    return y, mr, ab
+
+
+def gn_bf16_backward(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mr: torch.Tensor, ab: torch.Tensor,
+                     groups: int, silu: bool, dgamma: torch.Tensor, dbeta: torch.Tensor, accumulate: bool) -> torch.Tensor:
+    N, H, W, C = x.shape
+    L = _lib.lib()
+    ws = workspace(L.salun_gn_bf16_workspace_bytes(N, C, H * W, groups), x.device)
+    dx = torch.empty_like(x)
+    check(L.salun_gn_bf16_backward(_dev(dy, torch.bfloat16, "dy"), _dev(x, torch.bfloat16, "x"),
+                                   _dev(gamma, torch.float32, "gamma"), _dev(mr, torch.float32, "mr"),
+                                   _dev(ab, torch.float32, "ab"), c_void_p(dx.data_ptr()),
+                                   _dev(dgamma, torch.float32, "dgamma"), _dev(dbeta, torch.float32, "dbeta"), N, C, H * W,
+                                   groups, int(bool(silu)), int(bool(accumulate)), c_void_p(ws.data_ptr()),
+                                   c_size_t(ws.numel()), _stream()), "salun_gn_bf16_backward")
+    return dx
+
+
 # ------------------------------------------------------------------- fused BatchNorm
 def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
                num_batches_tracked=None):
@@ -442,6 +481,7 @@ def proximal_step(p: torch.Tensor, p0: torch.Tensor, ratio: int, scratch: Option
                   scratch_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """In place soft-threshold of `p` towards `p0` with threshold = the ratio-th smallest |p - p0|
     (RL_pro.py:52-60).  Returns the threshold as a 1-element device tensor (no host sync)."""
+    PARAM_EPOCH[0] += 1
     n = p.numel()
     if ratio < 1:
         raise IndexError("index -1 is out of bounds for dimension 0 with size 0")  # reference: topk(.., 0)[0][-1]

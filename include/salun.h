@@ -290,6 +290,25 @@ int salun_gn_bf16_backward(const uint16_t *dy /*dev*/, const uint16_t *x /*dev*/
                            float *dbeta /*dev*/, int N, int C, int HW, int G, int silu, int accumulate, void *ws /*dev*/,
                            size_t ws_bytes, salun_stream_t stream);
 
+/* ------------------------------------------------------------------ K13 --
+ * Fused scaled-dot-product attention on bf16 tokens (fp32 softmax / accumulation) — replaces
+ * `CrossAttention.forward` of SD/ldm/modules/attention.py:168-192 (q.k^T * scale -> softmax -> @ v, which materialises
+ * the (B*heads) x Nq x Nk score tensor) for the SD U-Net's self-attention (4096 / 1024 / 256 / 64 tokens) and
+ * cross-attention (77 text tokens), 8 heads of D = 40 / 80 / 160 channels (D in {8,16,32,40,64,80,160} supported).
+ * Tensors are [B, tokens, H, D] VIEWS: element (b, t, h, d) at b*bs + t*ld + h*D + d (elements); every (token, head)
+ * row must be 16-byte aligned.  `lse` ([B*H][Nq] fp32, log2-domain logsumexp of the scaled scores) is the forward's
+ * second output and the backward's input; `dsum` is [B*H][Nq] fp32 scratch; dq / dk / dv are written contiguous. */
+int salun_attn_supported(int D);
+int salun_attn_forward(const uint16_t *q /*dev*/, const uint16_t *k /*dev*/, const uint16_t *v /*dev*/, uint16_t *o /*dev*/,
+                       float *lse /*dev or NULL*/, int B, int H, int Nq, int Nk, int D, long long q_bs, int q_ld,
+                       long long k_bs, int k_ld, long long v_bs, int v_ld, long long o_bs, int o_ld, double scale,
+                       salun_stream_t stream);
+int salun_attn_backward(const uint16_t *q /*dev*/, const uint16_t *k /*dev*/, const uint16_t *v /*dev*/,
+                        const uint16_t *o /*dev*/, const uint16_t *d_o /*dev*/, const float *lse /*dev*/,
+                        uint16_t *dq /*dev*/, uint16_t *dk /*dev*/, uint16_t *dv /*dev*/, float *dsum /*dev*/, int B, int H,
+                        int Nq, int Nk, int D, long long q_bs, int q_ld, long long k_bs, int k_ld, long long v_bs, int v_ld,
+                        long long o_bs, int o_ld, long long do_bs, int do_ld, double scale, salun_stream_t stream);
+
 /* Fused BatchNorm2d (+ residual add) (+ ReLU), NCHW fp32, forward and backward — replaces the
  * bn -> relu / bn -> (+identity) -> relu chains of the classifier blocks
  *   (Classification/models/ResNet.py:108-125,307-309) that run as separate library launches.

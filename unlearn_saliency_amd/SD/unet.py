@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint as _ckpt
 
+from .. import ops
 from ..conv_bf16 import SalunConv2dBF16
 from ..norm import _GN_TYPES, fused_gn_act
 
@@ -131,9 +132,14 @@ class CrossAttention(nn.Module):
     def forward(self, x, context=None):
         context = x if context is None else context
         b, n, _ = x.shape
+        q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
+        if q.is_cuda and q.dtype == torch.bfloat16 and ops.attn_supported(self.dim_head):
+            # bf16 configuration: fused attention of csrc/salun_attn.hip reading the projections in place ([b, n, h, d] views)
+            heads = lambda t: t.view(b, t.shape[1], self.heads, self.dim_head)
+            o = ops.attention(heads(q), heads(k.to(torch.bfloat16)), heads(v.to(torch.bfloat16)), self.scale)
+            return self.to_out(o.view(b, n, self.heads * self.dim_head))
         split = lambda t: t.view(b, t.shape[1], self.heads, self.dim_head).transpose(1, 2)  # (b, h, tokens, d)
-        o = F.scaled_dot_product_attention(split(self.to_q(x)), split(self.to_k(context)), split(self.to_v(context)),
-                                           scale=self.scale)
+        o = F.scaled_dot_product_attention(split(q), split(k), split(v), scale=self.scale)
         return self.to_out(o.transpose(1, 2).reshape(b, n, self.heads * self.dim_head))
 
 

@@ -71,6 +71,9 @@ SIGNATURES = {
     "salun_gn_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
     "salun_gn_bf16_forward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_gn_bf16_backward": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "salun_attn_supported": (c_int, [c_int]),
+    "salun_attn_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [ctypes.c_longlong, c_int] * 4 + [c_double, c_void_p]),
+    "salun_attn_backward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [ctypes.c_longlong, c_int] * 5 + [c_double, c_void_p]),
     "salun_bn_workspace_bytes": (c_size_t, [c_int]),
     "salun_bn_forward": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_double, c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_bn_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),

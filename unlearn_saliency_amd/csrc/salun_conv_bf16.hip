@@ -481,11 +481,18 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const uint16_t *__restri
 }
 __global__ __launch_bounds__(256) void k_colsum_finish(const float *__restrict__ part, float *__restrict__ out, int K, int chunks,
                                                        int accumulate) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
+  __shared__ float s[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + cx;
   float t = 0.f;
-  for (int c = 0; c < chunks; ++c) t += part[(size_t)c * K + k];
-  out[k] = accumulate ? out[k] + t : t;
+  if (k < K)
+    for (int c = ry; c < chunks; c += 8) t += part[(size_t)c * K + k];
+  s[ry][cx] = t;
+  __syncthreads();
+  if (ry == 0 && k < K) {
+    t = ((s[0][cx] + s[1][cx]) + (s[2][cx] + s[3][cx])) + ((s[4][cx] + s[5][cx]) + (s[6][cx] + s[7][cx]));
+    out[k] = accumulate ? out[k] + t : t;
+  }
 }
 
 int wgrad_splits(int tiles, int chunks) {
@@ -686,7 +693,7 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
     float *cpart = a.part + (size_t)splits * R * R * K * C;
     hipLaunchKernelGGL(k_colsum_partial, dim3((K / 8 + 31) / 32, chunks), dim3(256), 0, st, dy, cpart, M, K, rpc);
     SALUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_colsum_finish, dim3((K + 255) / 256), dim3(256), 0, st, cpart, db, K, chunks, accumulate);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, cpart, db, K, chunks, accumulate);
     SALUN_LAUNCH_CHECK();
   }
   return SALUN_OK;

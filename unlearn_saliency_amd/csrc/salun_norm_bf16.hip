@@ -171,15 +171,23 @@ __global__ __launch_bounds__(64) void k_gn16_bwd_group(const float2 *__restrict_
   if (lane == 0) { gs[((size_t)n * G + g) * 2] = (float)s0; gs[((size_t)n * G + g) * 2 + 1] = (float)s1; }
 }
 
-// ---- parameter gradients: dbeta[c] = sum_{n,chunk} A, dgamma[c] = sum_{n,chunk} B (fixed order)
+// ---- parameter gradients: dbeta[c] = sum_{n,chunk} A, dgamma[c] = sum_{n,chunk} B; block = 32 channels x 8 lanes over
+// the (n, chunk) list, lane partials folded in a fixed order
 __global__ __launch_bounds__(256) void k_gn16_bwd_params(const float2 *__restrict__ part, float *__restrict__ dgamma,
                                                          float *__restrict__ dbeta, int C, int nchunks_total, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double sa[8][33], sb[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   double a = 0.0, b = 0.0;
-  for (int i = 0; i < nchunks_total; ++i) { const float2 v = part[(size_t)i * C + c]; a += (double)v.x; b += (double)v.y; }
-  dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-  dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+  if (c < C)
+    for (int i = ry; i < nchunks_total; i += 8) { const float2 v = part[(size_t)i * C + c]; a += (double)v.x; b += (double)v.y; }
+  sa[ry][cx] = a; sb[ry][cx] = b;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    for (int q = 1; q < 8; ++q) { a += sa[q][cx]; b += sb[q][cx]; }
+    dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+    dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+  }
 }
 
 // ---- backward apply: dx = rstd * (dz*gamma - (s1 + xhat*s2)/m)
@@ -271,7 +279,7 @@ SALUN_EXPORT int salun_gn_bf16_backward(const uint16_t *dy, const uint16_t *x, c
   SALUN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gn16_bwd_group, dim3(G, N), dim3(64), 0, st, part, gamma, gs, C, cpg, chunks);
   SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gn16_bwd_params, dim3((C + 255) / 256), dim3(256), 0, st, part, dgamma, dbeta, C, N * chunks, accumulate);
+  hipLaunchKernelGGL(k_gn16_bwd_params, dim3((C + 31) / 32), dim3(256), 0, st, part, dgamma, dbeta, C, N * chunks, accumulate);
   SALUN_LAUNCH_CHECK();
   const int64_t octets = (int64_t)N * HW * (C / 8);
   const int grid = salun_grid_for(octets, 256);

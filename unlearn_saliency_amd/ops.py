@@ -395,6 +395,77 @@ def gn_bf16_backward(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mr:
     return dx
 
 
+# ----------------------------------------------------------------------------- K13
+def attn_supported(D: int) -> bool:
+    return bool(_lib.lib().salun_attn_supported(int(D)))
+
+
+def _tok_view(t: torch.Tensor, name: str):
+    """[B, tokens, H, D] bf16 view -> (pointer, batch stride, token stride); head stride D, channel stride 1."""
+    if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4:
+        raise TypeError(f"{name}: expected a 4-D bfloat16 device tensor [B, tokens, H, D]")
+    B, N, H, D = t.shape
+    if t.stride(3) != 1 or (H > 1 and t.stride(2) != D):
+        raise ValueError(f"{name}: heads must be adjacent runs of D contiguous channels")
+    return c_void_p(t.data_ptr()), ctypes.c_longlong(t.stride(0) if B > 1 else N * t.stride(1)), c_int(t.stride(1))
+
+
+def attn_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, need_lse: bool = True):
+    """softmax(scale * q k^T) v over [B, tokens, H, D] bf16 views -> (o [B, Nq, H, D] contiguous, lse [B*H, Nq] or None)."""
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    o = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((B * H, Nq), dtype=torch.float32, device=q.device) if need_lse else None
+    qp, qb, ql = _tok_view(q, "q")
+    kp, kb, kl = _tok_view(k, "k")
+    vp, vb, vl = _tok_view(v, "v")
+    op, ob, ol = _tok_view(o, "o")
+    check(_lib.lib().salun_attn_forward(qp, kp, vp, op, c_void_p(lse.data_ptr() if need_lse else None), B, H, Nq, Nk, D,
+                                        qb, ql, kb, kl, vb, vl, ob, ol, c_double(scale), _stream()), "salun_attn_forward")
+    return o, lse
+
+
+def attn_backward(q, k, v, o, d_o, lse, scale: float):
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    dq = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
+    dk = torch.empty((B, Nk, H, D), dtype=torch.bfloat16, device=q.device)
+    dv = torch.empty((B, Nk, H, D), dtype=torch.bfloat16, device=q.device)
+    dsum = torch.empty((B * H, Nq), dtype=torch.float32, device=q.device)
+    qp, qb, ql = _tok_view(q, "q")
+    kp, kb, kl = _tok_view(k, "k")
+    vp, vb, vl = _tok_view(v, "v")
+    op, ob, ol = _tok_view(o, "o")
+    dp, db, dl = _tok_view(d_o, "d_o")
+    check(_lib.lib().salun_attn_backward(qp, kp, vp, op, dp, _dev(lse, torch.float32, "lse"), c_void_p(dq.data_ptr()),
+                                         c_void_p(dk.data_ptr()), c_void_p(dv.data_ptr()), c_void_p(dsum.data_ptr()),
+                                         B, H, Nq, Nk, D, qb, ql, kb, kl, vb, vl, ob, ol, db, dl, c_double(scale), _stream()),
+          "salun_attn_backward")
+    return dq, dk, dv
+
+
+class _Attn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        o, lse = attn_forward(q, k, v, scale, need_lse=True)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = float(scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        if d_o.stride(3) != 1 or d_o.stride(2) != d_o.shape[3]:
+            d_o = d_o.contiguous()
+        dq, dk, dv = attn_backward(q, k, v, o, d_o.to(torch.bfloat16), lse, ctx.scale)
+        return dq, dk, dv, None
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """Differentiable fused attention over [B, tokens, H, D] bf16 views (csrc/salun_attn.hip, K13)."""
+    return _Attn.apply(q, k, v, float(scale))
+
+
 # ------------------------------------------------------------------- fused BatchNorm
 def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
                num_batches_tracked=None):

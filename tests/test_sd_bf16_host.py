@@ -1,0 +1,51 @@
+"""Host side of the bf16 SD configuration (no GPU): which convolutions of the U-Net go to the bf16 MFMA kernels (K11),
+which stay on the fp32 kernels, that parameters / state_dict are untouched by the re-classing, and that the weight-pack
+cache is keyed on the parameter epoch the fused optimizers bump."""
+import torch
+
+from fixtures import sd_tiny_config
+
+
+def test_reclassing_covers_every_convolution_and_keeps_the_state_dict():
+    from unlearn_saliency_amd.SD.unet import UNetModel, V1_UNET_CONFIG
+    from unlearn_saliency_amd.conv_bf16 import SalunConv2dBF16, _Fp32Island, use_salun_convs_bf16
+    with torch.device("meta"):
+        m = UNetModel(**V1_UNET_CONFIG)
+    names = [n for n, _ in m.named_parameters()]
+    n16 = use_salun_convs_bf16(m)
+    convs = [mod for mod in m.modules() if isinstance(mod, torch.nn.Conv2d)]
+    assert all(isinstance(c, (SalunConv2dBF16, _Fp32Island)) for c in convs)
+    islands = [c for c in convs if isinstance(c, _Fp32Island)]
+    assert n16 == len(convs) - len(islands) == 96
+    # only the 4-channel latent head and tail stay fp32
+    assert sorted((c.in_channels, c.out_channels) for c in islands) == [(4, 320), (320, 4)]
+    assert [n for n, _ in m.named_parameters()] == names
+
+
+def test_pack_cache_key_follows_param_epoch():
+    from unlearn_saliency_amd import ops
+    from unlearn_saliency_amd.conv_bf16 import SalunConv2dBF16
+    calls = []
+    real = ops.conv2d_bf16_pack
+    ops.conv2d_bf16_pack = lambda w, out=None: calls.append(1) or torch.zeros(1)
+    try:
+        c = torch.nn.Conv2d(32, 32, 3, padding=1)
+        c.__class__ = SalunConv2dBF16
+        c.packed_weight(); c.packed_weight()
+        assert len(calls) == 1                      # cached
+        ops.PARAM_EPOCH[0] += 1                     # what masked_sgd_step / masked_adam_step / proximal_step do
+        c.packed_weight()
+        assert len(calls) == 2
+        with torch.no_grad():
+            c.weight.mul_(2.0)                      # torch's own version counter
+        c.packed_weight()
+        assert len(calls) == 3
+    finally:
+        ops.conv2d_bf16_pack = real
+
+
+def test_tiny_config_is_inside_the_bf16_kernels_domain():
+    from unlearn_saliency_amd.SD.unet import UNetModel
+    from unlearn_saliency_amd.conv_bf16 import use_salun_convs_bf16
+    m = UNetModel(**sd_tiny_config())
+    assert use_salun_convs_bf16(m) >= 8

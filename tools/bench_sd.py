@@ -119,7 +119,11 @@ def main():
                      "mean_launch_ms": tail_ms, "achieved": 29.0 * NS / (tail_ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": 29.0 * NS / (tail_ms * 1e-3) / 1e9 / 8000.0},
         "fwd_bwd": {"tflop_per_step": tflop, "achieved_TFLOPs": tflop / dt,
-                    "note": "3 fwd + 2 bwd + 2 checkpoint recomputes of 0.803 TFLOP/sample"},
+                    "peak_TFLOPs": 2500.0 if a.bf16 else 157.3, "frac": tflop / dt / (2500.0 if a.bf16 else 157.3),
+                    "note": "3 fwd + 2 bwd + 2 checkpoint recomputes of 0.803 TFLOP/sample; peak = dense bf16 / fp32 MFMA"},
+        "kernels": {"conv": "K11 bf16 NHWC MFMA" if (a.bf16 and n_salun) else ("K8 fp32 MFMA" if n_salun else "library"),
+                    "group_norm": "K12 bf16 NHWC" if a.bf16 else "fused fp32",
+                    "attention": "K13 fused bf16" if a.bf16 else "library scaled_dot_product_attention"},
         "hbm_peak_alloc_GB": torch.cuda.max_memory_allocated() / 1e9,
     }
     print(json.dumps(out))

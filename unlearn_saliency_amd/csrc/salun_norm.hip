@@ -536,18 +536,25 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
   }
 }
 
-// dgamma[c] = sum_n part[n][c] (fixed order), optionally also accumulated into the parameter's .grad storage
+// dgamma[c] = sum_n part[n][c] (fixed order), optionally also accumulated into the parameter's .grad storage.
+// Block = 32 channels x 8 lanes over n (a single thread per channel walked N = 128 rows one dependent load at a time).
 __global__ __launch_bounds__(256) void k_gn_bwd_final(const float *__restrict__ part_dgamma,
                                                       const float *__restrict__ part_dbeta, int N, int C,
                                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                       float *__restrict__ gacc, float *__restrict__ bacc) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double s_g[8][33], s_b[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   double sg = 0.0, sb = 0.0;
-  for (int n = 0; n < N; ++n) {
-    sg += (double)part_dgamma[(size_t)n * C + c];
-    sb += (double)part_dbeta[(size_t)n * C + c];
-  }
+  if (c < C)
+    for (int n = ry; n < N; n += 8) {
+      sg += (double)part_dgamma[(size_t)n * C + c];
+      sb += (double)part_dbeta[(size_t)n * C + c];
+    }
+  s_g[ry][cx] = sg; s_b[ry][cx] = sb;
+  __syncthreads();
+  if (ry != 0 || c >= C) return;
+  for (int q = 1; q < 8; ++q) { sg += s_g[q][cx]; sb += s_b[q][cx]; }
   dgamma[c] = (float)sg;
   dbeta[c] = (float)sb;
   if (gacc) gacc[c] += (float)sg;
@@ -629,7 +636,7 @@ SALUN_EXPORT int salun_gn_backward(const float *dz, const float *x, const float 
 #undef SALUN_GN_BWD_I
 #undef SALUN_GN_BWD
   SALUN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, st, pg, pb, N, C, dgamma, dbeta,
+  hipLaunchKernelGGL(k_gn_bwd_final, dim3((C + 31) / 32), dim3(256), 0, st, pg, pb, N, C, dgamma, dbeta,
                      grad_gamma_acc, grad_beta_acc);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;

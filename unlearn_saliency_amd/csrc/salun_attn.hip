@@ -26,11 +26,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }  // v_cvt_pk_bf16_f32: RNE
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  bf16x2_t v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
@@ -47,7 +48,7 @@ __device__ __forceinline__ bf16x8 tr_operand(const char *lds_base, uint32_t byte
 __device__ __forceinline__ bf16x8 pack_operand(const float *f) {
   union { uint32_t w[4]; bf16x8 v; } u;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) u.w[j] = (uint32_t)f2bf(f[2 * j]) | ((uint32_t)f2bf(f[2 * j + 1]) << 16);
+  for (int j = 0; j < 4; ++j) u.w[j] = pack2(f[2 * j], f[2 * j + 1]);
   return u.v;
 }
 __device__ __forceinline__ bf16x8 zero_operand() {
@@ -151,8 +152,8 @@ __device__ __forceinline__ void store_token_rows(const f32x16 (&acc)[Geo<D>::NT]
     for (int a = 0; a < 4; ++a) {
       const int d0 = t * 32 + 8 * a + 4 * half;
       if (d0 < D) {
-        const uint32_t lo = (uint32_t)f2bf(acc[t][4 * a] * mul) | ((uint32_t)f2bf(acc[t][4 * a + 1] * mul) << 16);
-        const uint32_t hi = (uint32_t)f2bf(acc[t][4 * a + 2] * mul) | ((uint32_t)f2bf(acc[t][4 * a + 3] * mul) << 16);
+        const uint32_t lo = pack2(acc[t][4 * a] * mul, acc[t][4 * a + 1] * mul);
+        const uint32_t hi = pack2(acc[t][4 * a + 2] * mul, acc[t][4 * a + 3] * mul);
         *reinterpret_cast<uint2 *>(row + d0) = make_uint2(lo, hi);
       }
     }
@@ -211,16 +212,26 @@ __global__ __launch_bounds__(256) void attn_fwd(const AttnArgs g) {
       }
     }
     float mx = -INFINITY;
-    const int key0 = kt * KT + 4 * half;
+    if ((kt + 1) * KT > g.Nk) {  // ragged last tile (wave-uniform): keys past the end score -inf
+      const int key0 = kt * KT + 4 * half;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int key = key0 + sub * 32 + (v & 3) + 8 * (v >> 2);
-        const float x = key < g.Nk ? s[sub][v] * c : -INFINITY;
-        s[sub][v] = x;
-        mx = fmaxf(mx, x);
-      }
+        for (int v = 0; v < 16; ++v) {
+          const int key = key0 + sub * 32 + (v & 3) + 8 * (v >> 2);
+          const float x = key < g.Nk ? s[sub][v] * c : -INFINITY;
+          s[sub][v] = x;
+          mx = fmaxf(mx, x);
+        }
+    } else {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          s[sub][v] *= c;
+          mx = fmaxf(mx, s[sub][v]);
+        }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);  // finite: every tile holds at least one valid key
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);

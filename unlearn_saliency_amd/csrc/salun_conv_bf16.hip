@@ -34,11 +34,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 // round-to-nearest-even, NaN -> quiet NaN (what torch's float -> bfloat16 does)
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }  // v_cvt_pk_bf16_f32: RNE
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  bf16x2_t v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void k_pack_w(const float *__restrict__ w, uin
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      o[j] = (uint32_t)f2bf(src[(2 * j) * RS]) | ((uint32_t)f2bf(src[(2 * j + 1) * RS]) << 16);
+      o[j] = pack2(src[(2 * j) * RS], src[(2 * j + 1) * RS]);
     *reinterpret_cast<uint4 *>(wp + (kr * C + (int64_t)c8 * 8)) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float *__restrict__
     }
     uint32_t o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+    for (int j = 0; j < 4; ++j) o[j] = pack2(v[2 * j], v[2 * j + 1]);
     *reinterpret_cast<uint4 *>(y + (int64_t)m * K + k) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }

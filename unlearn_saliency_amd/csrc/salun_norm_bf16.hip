@@ -15,11 +15,12 @@
 
 namespace {
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }  // v_cvt_pk_bf16_f32: RNE
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  bf16x2_t v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
@@ -30,7 +31,7 @@ __device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   uint32_t o[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (uint32_t)f2bf(f[2 * j]) | ((uint32_t)f2bf(f[2 * j + 1]) << 16);
+  for (int j = 0; j < 4; ++j) o[j] = pack2(f[2 * j], f[2 * j + 1]);
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 

@@ -21,9 +21,13 @@
 //                  immediate offset into the same input patch: 9 accumulators per wave, one staged patch per 64 pixels.
 //                  Pixel ranges are split over workgroups -> fp32 partials -> fixed-order reduce into OIHW (no atomics).
 //
-// Workgroup = 256 threads = 4 waves, each wave a 64x64 result tile (2x2 MFMA tiles, 64 fp32 accumulators); LDS double
+// Workgroup = 4 or 8 waves, each wave a 64x64 result tile (2x2 MFMA tiles, 64 fp32 accumulators); LDS double
 // buffered, global loads of stage i+1 in flight under the MFMAs of stage i, one barrier per stage.
 #include "salun_common.h"
+
+#ifndef SALUN_BF16_TILE
+#define SALUN_BF16_TILE 0  // lab builds (tools/_run_bf16_lab.sh) pin one tile shape; 0 = choose per problem
+#endif
 
 namespace {
 
@@ -94,15 +98,16 @@ struct IgArgs {
 };
 
 template <int WM, int WN, int BK, bool BTR>
-__global__ __launch_bounds__(256) void conv_bf16_igemm(const IgArgs g) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_igemm(const IgArgs g) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int NTHR = 64 * WM * WN;           // one wave per 64x64 result tile
   constexpr int CPR = BK / 8;                 // 16-byte chunks per A row
   constexpr int ROWB = BK * 2 + 16;           // padded LDS row (conflict-free ds_read_b128 across 16 rows)
-  constexpr int NA = BM * CPR / 256;          // A chunks per thread per stage
+  constexpr int NA = BM * CPR / NTHR;          // A chunks per thread per stage
   constexpr int A_BYTES = BM * ROWB;
   constexpr int B_BYTES = BTR ? (BN / 32) * (BK * 64) : BN * ROWB;
-  constexpr int NB = BTR ? (BK * BN / 8) / 256 : BN * CPR / 256;
-  static_assert(WM * WN == 4 && NA >= 1 && NB >= 1, "tile");
+  constexpr int NB = BTR ? (BK * BN / 8) / NTHR : BN * CPR / NTHR;
+  static_assert((WM * WN == 4 || WM * WN == 8) && NA >= 1 && NB >= 1, "tile");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // buffer b: A at b*STAGE_BYTES, B behind it
 
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_bf16_igemm(const IgArgs g) {
   int a_hb[NA], a_wb[NA], a_nb[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = tid / CPR + (256 / CPR) * i;
+    const int row = tid / CPR + (NTHR / CPR) * i;
     const int m = m0 + row;
     if (m < g.M) {
       const int n = m / (g.OH * g.OW);
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_bf16_igemm(const IgArgs g) {
     if (!BTR) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int row = tid / CPR + (256 / CPR) * i;
+        const int row = tid / CPR + (NTHR / CPR) * i;
         const int k = n0 + row;
         rb[i] = make_uint4(0, 0, 0, 0);
         if (k < g.Kout) rb[i] = *reinterpret_cast<const uint4 *>(g.wp + (((size_t)k * RS + tap) * g.Cin + c0 + a_cc * 8));
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_bf16_igemm(const IgArgs g) {
       const int tapf = RS - 1 - tap;
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTHR * i;
         const int row = id / CPB, cc = id - row * CPB;
         const int col = n0 + cc * 8;
         rb[i] = make_uint4(0, 0, 0, 0);
@@ -171,20 +176,20 @@ __global__ __launch_bounds__(256) void conv_bf16_igemm(const IgArgs g) {
   auto store_stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int row = tid / CPR + (256 / CPR) * i;
+      const int row = tid / CPR + (NTHR / CPR) * i;
       *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + row * ROWB + a_cc * 16) = ra[i];
     }
     if (!BTR) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int row = tid / CPR + (256 / CPR) * i;
+        const int row = tid / CPR + (NTHR / CPR) * i;
         *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + row * ROWB + a_cc * 16) = rb[i];
       }
     } else {
       constexpr int CPB = BN / 8;
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTHR * i;
         const int row = id / CPB, cc = id - row * CPB;
         *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + (cc >> 2) * (BK * 64) + row * 64 + (cc & 3) * 16) = rb[i];
       }
@@ -545,7 +550,7 @@ int launch_igemm(IgArgs a, void *ws, size_t ws_bytes, hipStream_t st) {
   if (sp.splits > 1 && (!ws || ws_bytes < (size_t)sp.splits * a.M * a.Kout * sizeof(float))) sp = {1, nstage};
   a.stages_per_split = sp.per;
   a.part = sp.splits > 1 ? static_cast<float *>(ws) : nullptr;
-  hipLaunchKernelGGL((conv_bf16_igemm<WM, WN, BK, BTR>), dim3(mt, nt, sp.splits), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_bf16_igemm<WM, WN, BK, BTR>), dim3(mt, nt, sp.splits), dim3(64 * WM * WN), lds, st, a);
   SALUN_LAUNCH_CHECK();
   if (sp.splits > 1) {
     const int64_t total = (int64_t)a.M * (a.Kout / 8);
@@ -556,10 +561,6 @@ int launch_igemm(IgArgs a, void *ws, size_t ws_bytes, hipStream_t st) {
   return SALUN_OK;
 }
 
-#ifndef SALUN_BF16_TILE
-#define SALUN_BF16_TILE 0  // lab builds (tools/_run_bf16_lab.sh) pin one tile shape; 0 = choose per problem
-#endif
-
 template <bool BTR>
 int dispatch_igemm(const IgArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
   const int bk64 = (a.Cin % 64 == 0);
@@ -567,6 +568,11 @@ int dispatch_igemm(const IgArgs &a, void *ws, size_t ws_bytes, hipStream_t st) {
   if (SALUN_BF16_TILE == 2) return launch_igemm<2, 2, 32, BTR>(a, ws, ws_bytes, st);
   if (SALUN_BF16_TILE == 3 && bk64) return launch_igemm<4, 1, 64, BTR>(a, ws, ws_bytes, st);
   if (SALUN_BF16_TILE == 4) return launch_igemm<4, 1, 32, BTR>(a, ws, ws_bytes, st);
+  if (SALUN_BF16_TILE == 5) return launch_igemm<4, 2, 32, BTR>(a, ws, ws_bytes, st);
+  if (SALUN_BF16_TILE == 6) return launch_igemm<2, 4, 32, BTR>(a, ws, ws_bytes, st);
+  // 128 x 256 (eight waves) where the channel count tiles it: a third less operand traffic per MFMA, +5..13 % on the
+  // 1280-channel levels; 128 x 128 otherwise (K = 320 / 640 would pad a 256-wide tile by 37 % / 17 %)
+  if (a.Kout % 256 == 0) return launch_igemm<2, 4, 32, BTR>(a, ws, ws_bytes, st);
   return launch_igemm<2, 2, 32, BTR>(a, ws, ws_bytes, st);
 }
 
@@ -609,14 +615,19 @@ SALUN_EXPORT size_t salun_conv2d_bf16_data_workspace_bytes(int N, int H, int W, 
   if (!supported(C, K, R, stride, pad) || N < 1 || H < 1 || W < 1) return 0;
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
   const int BK = 32;
+  // tile of the variant dispatch_igemm picks (lab builds pin others)
+  const int BMt = (SALUN_BF16_TILE == 3 || SALUN_BF16_TILE == 4 || SALUN_BF16_TILE == 5) ? 256 : 128;
+  const int BNt = (SALUN_BF16_TILE == 3 || SALUN_BF16_TILE == 4) ? 64 : (SALUN_BF16_TILE == 6 ? 256 : 128);
+  const int BNf = (SALUN_BF16_TILE == 0 && K % 256 == 0) ? 256 : BNt;  // forward: output channels K
+  const int BNd = (SALUN_BF16_TILE == 0 && C % 256 == 0) ? 256 : BNt;  // backward-data: output channels C
   size_t need = 0;
   {  // forward
-    const int M = N * OH * OW, tiles = ((M + 127) / 128) * ((K + 127) / 128);
+    const int M = N * OH * OW, tiles = ((M + BMt - 1) / BMt) * ((K + BNf - 1) / BNf);
     const SplitPlan sp = plan_split(tiles, R * R * (C / BK));
     if (sp.splits > 1) need = (size_t)sp.splits * M * K * sizeof(float);
   }
   {  // backward-data
-    const int M = N * H * W, tiles = ((M + 127) / 128) * ((C + 127) / 128);
+    const int M = N * H * W, tiles = ((M + BMt - 1) / BMt) * ((C + BNd - 1) / BNd);
     const SplitPlan sp = plan_split(tiles, R * R * (K / BK));
     const size_t b = sp.splits > 1 ? (size_t)sp.splits * M * C * sizeof(float) : 0;
     if (b > need) need = b;

@@ -309,6 +309,25 @@ int salun_attn_backward(const uint16_t *q /*dev*/, const uint16_t *k /*dev*/, co
                         int Nq, int Nk, int D, long long q_bs, int q_ld, long long k_bs, int k_ld, long long v_bs, int v_ld,
                         long long o_bs, int o_ld, long long do_bs, int do_ld, double scale, salun_stream_t stream);
 
+/* ------------------------------------------------------------------ K14 --
+ * Token-wise layers of the SD transformer blocks on bf16 tokens, fp32 arithmetic, one pass each:
+ *   LayerNorm  (SD/ldm/modules/attention.py:196-216, `nn.LayerNorm(dim)` x3 per BasicTransformerBlock):
+ *     forward  y[rows][C] = gamma*(x-mean)*rstd + beta, stats[rows][2] = (mean, rstd) for the backward
+ *     backward dx, dgamma / dbeta (fp32, = or +=; per-workgroup partials in `ws`, folded in a fixed order)
+ *   GEGLU      (attention.py:37-46: `x, gate = proj(x).chunk(2, dim=-1); x * F.gelu(gate)`, erf form):
+ *     forward  out[rows][F] = h[:, :F] * gelu(h[:, F:]);  backward dh[rows][2F] from h and d(out).
+ * C % 8 == 0, C <= 2048, F % 8 == 0; x / y / h / out 16-byte aligned; gamma / beta may be any fp32 slice. */
+size_t salun_ln_bf16_workspace_bytes(int64_t rows, int C);
+int salun_ln_bf16_forward(const uint16_t *x /*dev*/, const float *gamma /*dev*/, const float *beta /*dev*/,
+                          uint16_t *y /*dev*/, float *stats /*dev or NULL*/, int64_t rows, int C, double eps,
+                          salun_stream_t stream);
+int salun_ln_bf16_backward(const uint16_t *dy /*dev*/, const uint16_t *x /*dev*/, const float *gamma /*dev*/,
+                           const float *stats /*dev*/, uint16_t *dx /*dev*/, float *dgamma /*dev*/, float *dbeta /*dev*/,
+                           int64_t rows, int C, int accumulate, void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+int salun_geglu_bf16_forward(const uint16_t *h /*dev*/, uint16_t *out /*dev*/, int64_t rows, int F, salun_stream_t stream);
+int salun_geglu_bf16_backward(const uint16_t *h /*dev*/, const uint16_t *dy /*dev*/, uint16_t *dh /*dev*/, int64_t rows,
+                              int F, salun_stream_t stream);
+
 /* Fused BatchNorm2d (+ residual add) (+ ReLU), NCHW fp32, forward and backward — replaces the
  * bn -> relu / bn -> (+identity) -> relu chains of the classifier blocks
  *   (Classification/models/ResNet.py:108-125,307-309) that run as separate library launches.

@@ -123,7 +123,8 @@ def main():
                     "note": "3 fwd + 2 bwd + 2 checkpoint recomputes of 0.803 TFLOP/sample; peak = dense bf16 / fp32 MFMA"},
         "kernels": {"conv": "K11 bf16 NHWC MFMA" if (a.bf16 and n_salun) else ("K8 fp32 MFMA" if n_salun else "library"),
                     "group_norm": "K12 bf16 NHWC" if a.bf16 else "fused fp32",
-                    "attention": "K13 fused bf16" if a.bf16 else "library scaled_dot_product_attention"},
+                    "attention": "K13 fused bf16" if a.bf16 else "library scaled_dot_product_attention",
+                    "layer_norm_geglu": "K14 bf16 tokens" if a.bf16 else "library"},
         "hbm_peak_alloc_GB": torch.cuda.max_memory_allocated() / 1e9,
     }
     print(json.dumps(out))

@@ -149,7 +149,10 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        x, gate = self.proj(x).chunk(2, dim=-1)
+        h = self.proj(x)
+        if h.is_cuda and h.dtype == torch.bfloat16 and h.shape[-1] % 16 == 0:
+            return ops.geglu_bf16(h)  # one pass (csrc/salun_tok_bf16.hip) instead of chunk -> gelu -> mul
+        x, gate = h.chunk(2, dim=-1)
         return x * F.gelu(gate)
 
 
@@ -173,10 +176,18 @@ class BasicTransformerBlock(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
         self.use_checkpoint = use_checkpoint
 
+    @staticmethod
+    def _ln(ln, x):
+        # bf16 tokens: LayerNorm in one pass with bf16 output (autocast would cast to fp32, normalise, and leave an fp32
+        # tensor for the next Linear to cast back)
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048:
+            return ops.layer_norm_bf16(x, ln)
+        return ln(x)
+
     def _forward(self, x, context):
-        x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), context) + x
-        return self.ff(self.norm3(x)) + x
+        x = self.attn1(self._ln(self.norm1, x)) + x
+        x = self.attn2(self._ln(self.norm2, x), context) + x
+        return self.ff(self._ln(self.norm3, x)) + x
 
     def forward(self, x, context=None):
         if self.use_checkpoint and torch.is_grad_enabled():

@@ -74,6 +74,11 @@ SIGNATURES = {
     "salun_attn_supported": (c_int, [c_int]),
     "salun_attn_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [ctypes.c_longlong, c_int] * 4 + [c_double, c_void_p]),
     "salun_attn_backward": (c_int, [c_void_p] * 10 + [c_int] * 5 + [ctypes.c_longlong, c_int] * 5 + [c_double, c_void_p]),
+    "salun_ln_bf16_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "salun_ln_bf16_forward": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_double, c_void_p]),
+    "salun_ln_bf16_backward": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "salun_geglu_bf16_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "salun_geglu_bf16_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "salun_bn_workspace_bytes": (c_size_t, [c_int]),
     "salun_bn_forward": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_double, c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_bn_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),

@@ -466,6 +466,81 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -
     return _Attn.apply(q, k, v, float(scale))
 
 
+# ----------------------------------------------------------------------------- K14
+class _LayerNorm16(torch.autograd.Function):
+    """LayerNorm over the last dimension of a bf16 token tensor (csrc/salun_tok_bf16.hip): bf16 in / out, fp32 stats."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        C = x.shape[-1]
+        xc = x.contiguous()
+        rows = xc.numel() // C
+        y = torch.empty_like(xc)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        check(_lib.lib().salun_ln_bf16_forward(_dev(xc, torch.bfloat16, "x"), _dev(weight, torch.float32, "gamma"),
+                                               _dev(bias, torch.float32, "beta"), c_void_p(y.data_ptr()),
+                                               c_void_p(stats.data_ptr()), c_int64(rows), C, c_double(eps), _stream()),
+              "salun_ln_bf16_forward")
+        ctx.save_for_backward(xc, weight, bias, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import gradsink
+        xc, weight, bias, stats = ctx.saved_tensors
+        C = xc.shape[-1]
+        rows = xc.numel() // C
+        dyc = dy.to(torch.bfloat16).contiguous()
+        L = _lib.lib()
+        ws = workspace(L.salun_ln_bf16_workspace_bytes(c_int64(rows), C), xc.device)
+        gw, gb = gradsink.sink(weight), gradsink.sink(bias)
+        sunk = gw is not None and gb is not None
+        if not sunk:
+            gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+        dx = torch.empty_like(xc)
+        check(L.salun_ln_bf16_backward(_dev(dyc, torch.bfloat16, "dy"), _dev(xc, torch.bfloat16, "x"),
+                                       _dev(weight, torch.float32, "gamma"), _dev(stats, torch.float32, "stats"),
+                                       c_void_p(dx.data_ptr()), _dev(gw, torch.float32, "dgamma"),
+                                       _dev(gb, torch.float32, "dbeta"), c_int64(rows), C, int(sunk),
+                                       c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()), "salun_ln_bf16_backward")
+        return dx, (None if sunk else gw), (None if sunk else gb), None
+
+
+def layer_norm_bf16(x: torch.Tensor, ln: "torch.nn.LayerNorm") -> torch.Tensor:
+    return _LayerNorm16.apply(x, ln.weight, ln.bias, float(ln.eps))
+
+
+class _Geglu16(torch.autograd.Function):
+    """out = h[..., :F] * gelu(h[..., F:]) on a bf16 tensor (csrc/salun_tok_bf16.hip)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        hc = h.contiguous()
+        F2 = hc.shape[-1]
+        rows = hc.numel() // F2
+        out = torch.empty(hc.shape[:-1] + (F2 // 2,), dtype=torch.bfloat16, device=h.device)
+        check(_lib.lib().salun_geglu_bf16_forward(_dev(hc, torch.bfloat16, "h"), c_void_p(out.data_ptr()), c_int64(rows),
+                                                  F2 // 2, _stream()), "salun_geglu_bf16_forward")
+        ctx.save_for_backward(hc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (hc,) = ctx.saved_tensors
+        F2 = hc.shape[-1]
+        rows = hc.numel() // F2
+        dyc = dy.to(torch.bfloat16).contiguous()
+        dh = torch.empty_like(hc)
+        check(_lib.lib().salun_geglu_bf16_backward(_dev(hc, torch.bfloat16, "h"), _dev(dyc, torch.bfloat16, "dy"),
+                                                   c_void_p(dh.data_ptr()), c_int64(rows), F2 // 2, _stream()),
+              "salun_geglu_bf16_backward")
+        return dh
+
+
+def geglu_bf16(h: torch.Tensor) -> torch.Tensor:
+    return _Geglu16.apply(h)
+
+
 # ------------------------------------------------------------------- fused BatchNorm
 def bn_forward(x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
                num_batches_tracked=None):

@@ -98,7 +98,8 @@ struct IgArgs {
 };
 
 template <int WM, int WN, int BK, bool BTR>
-__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_igemm(const IgArgs g) {
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, (WM * WN == 4 && BK == 32) ? 3 : 2)))
+void conv_bf16_igemm(const IgArgs g) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int NTHR = 64 * WM * WN;           // one wave per 64x64 result tile
   constexpr int CPR = BK / 8;                 // 16-byte chunks per A row
@@ -138,8 +139,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_igemm(const IgArgs g) 
       a_hb[i] = -(1 << 20); a_wb[i] = 0; a_nb[i] = 0;  // never in range
     }
   }
-  uint4 ra[NA], rb[NB];
-  auto load_stage = [&](int st) {
+  // Staging is BRANCH FREE: every load is issued unconditionally from a clamped (always valid) address and zero-filled
+  // rows are masked when the registers are written to LDS.  With a branch around a load hipcc cannot count the loads in
+  // flight and waits `vmcnt(0)` before the LDS write — which would also drain the loads of the stage after next and
+  // collapse the two-deep register ring below to depth one (measured: the ring then changes nothing).
+  int wb_base[NB];  // per-thread constant part of the weight offsets (elements)
+  if (!BTR) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = tid / CPR + (NTHR / CPR) * i;
+      const int k = min(n0 + row, g.Kout - 1);  // rows past the last channel re-read it: their results are never stored
+      wb_base[i] = k * RS * g.Cin + a_cc * 8;
+    }
+  } else {
+    constexpr int CPB = BN / 8;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int id = tid + NTHR * i;
+      const int row = id / CPB, cc = id - row * CPB;
+      wb_base[i] = row * RS * g.Cf + min(n0 + cc * 8, g.Kout - 8);
+    }
+  }
+  uint4 r0[NA + NB], r1[NA + NB];  // one register set = the A chunks followed by the B chunks of a stage
+  uint32_t ma0[NA], ma1[NA];
+  auto load_stage = [&](int st, uint4 (&rr)[NA + NB], uint32_t (&ma)[NA]) {
     const int tap = st / cchunks, c0 = (st - tap * cchunks) * BK;
     const int r = tap / g.R, s = tap - r * g.R;
 #pragma unroll
@@ -148,42 +171,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_igemm(const IgArgs g) 
       bool ok = true;
       if (g.up == 2) { ok = !((vh | vw) & 1); vh >>= 1; vw >>= 1; }
       ok = ok && vh >= 0 && vh < g.H && vw >= 0 && vw < g.W;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (ok) ra[i] = *reinterpret_cast<const uint4 *>(g.x + ((size_t)(a_nb[i] + vh * g.W + vw) * g.Cin + c0 + a_cc * 8));
+      const uint32_t pix = (uint32_t)(a_nb[i] + __mul24(vh, g.W) + vw);        // < 2^24 pixels
+      const uint32_t off = ok ? __umul24(pix, (uint32_t)g.Cin) + (uint32_t)(c0 + a_cc * 8) : 0u;
+      ma[i] = ok ? 0xffffffffu : 0u;
+      rr[i] = *reinterpret_cast<const uint4 *>(g.x + off);
     }
-    if (!BTR) {
+    const int wu = BTR ? (c0 * RS + (RS - 1 - tap)) * g.Cf : tap * g.Cin + c0;  // wave-uniform part
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int row = tid / CPR + (NTHR / CPR) * i;
-        const int k = n0 + row;
-        rb[i] = make_uint4(0, 0, 0, 0);
-        if (k < g.Kout) rb[i] = *reinterpret_cast<const uint4 *>(g.wp + (((size_t)k * RS + tap) * g.Cin + c0 + a_cc * 8));
-      }
-    } else {
-      // backward-data: reduction row = forward out channel kf = c0 + row, flipped tap, columns = forward in channels
-      constexpr int CPB = BN / 8;  // chunks per reduction row
-      const int tapf = RS - 1 - tap;
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int id = tid + NTHR * i;
-        const int row = id / CPB, cc = id - row * CPB;
-        const int col = n0 + cc * 8;
-        rb[i] = make_uint4(0, 0, 0, 0);
-        if (col < g.Kout) rb[i] = *reinterpret_cast<const uint4 *>(g.wp + (((size_t)(c0 + row) * RS + tapf) * g.Cf + col));
-      }
-    }
+    for (int i = 0; i < NB; ++i) rr[NA + i] = *reinterpret_cast<const uint4 *>(g.wp + (uint32_t)(wb_base[i] + wu));
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, const uint4 (&rr)[NA + NB], const uint32_t (&ma)[NA]) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int row = tid / CPR + (NTHR / CPR) * i;
-      *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + row * ROWB + a_cc * 16) = ra[i];
+      *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + row * ROWB + a_cc * 16) =
+          make_uint4(rr[i].x & ma[i], rr[i].y & ma[i], rr[i].z & ma[i], rr[i].w & ma[i]);
     }
     if (!BTR) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int row = tid / CPR + (NTHR / CPR) * i;
-        *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + row * ROWB + a_cc * 16) = rb[i];
+        *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + row * ROWB + a_cc * 16) = rr[NA + i];
       }
     } else {
       constexpr int CPB = BN / 8;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_igemm(const IgArgs g) 
       for (int i = 0; i < NB; ++i) {
         const int id = tid + NTHR * i;
         const int row = id / CPB, cc = id - row * CPB;
-        *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + (cc >> 2) * (BK * 64) + row * 64 + (cc & 3) * 16) = rb[i];
+        *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + (cc >> 2) * (BK * 64) + row * 64 + (cc & 3) * 16) = rr[NA + i];
       }
     }
   };
@@ -210,12 +218,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_igemm(const IgArgs g) 
   const int gq = lane >> 4, sl = lane & 15;
   const uint32_t btr_off = (uint32_t)((wn * 2) * (BK * 64) + (8 * (gq >> 1) + (sl >> 2)) * 64 + (16 * (gq & 1) + 4 * (sl & 3)) * 2);
 
-  load_stage(st_begin);
-  store_stage(0);
-  __syncthreads();
-  for (int st = st_begin; st < st_end; ++st) {
-    const int buf = (st - st_begin) & 1;
-    if (st + 1 < st_end) load_stage(st + 1);
+  auto compute = [&](int buf) {
     const char *A = lds + buf * STAGE_BYTES, *B = A + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -234,7 +237,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_igemm(const IgArgs g) 
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (st + 1 < st_end) store_stage(buf ^ 1);
+  };
+  // Two-deep register ring over a double-buffered LDS tile: while stage s is multiplied, stage s+1 sits in registers
+  // (written to the other LDS buffer after the MFMAs) and the loads of stage s+2 are issued into the set stage s left.
+  // Stages are taken in pairs (static register naming); a stage index past the end re-loads the last stage with its
+  // A rows masked to zero, so an odd count costs one idle multiply instead of a branch inside the loop.
+  const int last = st_end - 1;
+  load_stage(st_begin, r0, ma0);
+  load_stage(min(st_begin + 1, last), r1, ma1);
+  if (st_begin + 1 > last) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ma1[i] = 0u;
+  }
+  store_stage(0, r0, ma0);
+  __syncthreads();
+  for (int st = st_begin; st < st_end; st += 2) {
+    load_stage(min(st + 2, last), r0, ma0);
+    if (st + 2 > last) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ma0[i] = 0u;
+    }
+    compute(0);
+    store_stage(1, r1, ma1);
+    __syncthreads();
+    load_stage(min(st + 3, last), r1, ma1);
+    if (st + 3 > last) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ma1[i] = 0u;
+    }
+    compute(1);
+    store_stage(0, r0, ma0);
     __syncthreads();
   }
   if (g.part) {  // split reduction: raw fp32 tile, finished by k_splitk_finish

@@ -98,7 +98,7 @@ struct IgArgs {
 };
 
 template <int WM, int WN, int BK, bool BTR>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, (WM * WN == 4 && BK == 32) ? 3 : 2)))
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu((WM * WN == 4 && BK == 32) ? 3 : 2, (WM * WN == 4 && BK == 32) ? 3 : 2)))
 void conv_bf16_igemm(const IgArgs g) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int NTHR = 64 * WM * WN;           // one wave per 64x64 result tile
@@ -160,8 +160,8 @@ void conv_bf16_igemm(const IgArgs g) {
       wb_base[i] = row * RS * g.Cf + min(n0 + cc * 8, g.Kout - 8);
     }
   }
-  uint4 r0[NA + NB], r1[NA + NB];  // one register set = the A chunks followed by the B chunks of a stage
-  uint32_t ma0[NA], ma1[NA];
+  uint4 r0[NA + NB], r1[NA + NB], r2[NA + NB];  // one register set = the A chunks followed by the B chunks of a stage
+  uint32_t ma0[NA], ma1[NA], ma2[NA];
   auto load_stage = [&](int st, uint4 (&rr)[NA + NB], uint32_t (&ma)[NA]) {
     const int tap = st / cchunks, c0 = (st - tap * cchunks) * BK;
     const int r = tap / g.R, s = tap - r * g.R;
@@ -240,35 +240,38 @@ void conv_bf16_igemm(const IgArgs g) {
   };
   // Two-deep register ring over a double-buffered LDS tile: while stage s is multiplied, stage s+1 sits in registers
   // (written to the other LDS buffer after the MFMAs) and the loads of stage s+2 are issued into the set stage s left.
-  // Stages are taken in pairs (static register naming); a stage index past the end re-loads the last stage with its
-  // A rows masked to zero, so an odd count costs one idle multiply instead of a branch inside the loop.
+  // Stages are taken three at a time (static register naming, three register sets: the loads of stages s+1 .. s+3 are
+  // in flight while stage s is multiplied); a stage index past the end re-loads the last stage with its A rows masked to
+  // zero, so a count that is not a multiple of three costs idle multiplies instead of branches inside the loop (a
+  // wave-uniform skip of those multiplies was tried: it cost backward-data its register budget, 2.07 -> 3.04 ms).
   const int last = st_end - 1;
-  load_stage(st_begin, r0, ma0);
-  load_stage(min(st_begin + 1, last), r1, ma1);
-  if (st_begin + 1 > last) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) ma1[i] = 0u;
+#define SALUN_IG_LOAD(S, R, M)                       \
+  load_stage(min((S), last), R, M);                  \
+  if ((S) > last) {                                  \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) M[i] = 0u; \
   }
+  SALUN_IG_LOAD(st_begin, r0, ma0)
+  SALUN_IG_LOAD(st_begin + 1, r1, ma1)
+  SALUN_IG_LOAD(st_begin + 2, r2, ma2)
   store_stage(0, r0, ma0);
   __syncthreads();
-  for (int st = st_begin; st < st_end; st += 2) {
-    load_stage(min(st + 2, last), r0, ma0);
-    if (st + 2 > last) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) ma0[i] = 0u;
-    }
-    compute(0);
-    store_stage(1, r1, ma1);
+  int buf = 0;
+  for (int st = st_begin; st < st_end; st += 3) {
+    SALUN_IG_LOAD(st + 3, r0, ma0)
+    compute(buf);
+    store_stage(buf ^ 1, r1, ma1);
     __syncthreads();
-    load_stage(min(st + 3, last), r1, ma1);
-    if (st + 3 > last) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) ma1[i] = 0u;
-    }
-    compute(1);
-    store_stage(0, r0, ma0);
+    SALUN_IG_LOAD(st + 4, r1, ma1)
+    compute(buf ^ 1);
+    store_stage(buf, r2, ma2);
     __syncthreads();
+    SALUN_IG_LOAD(st + 5, r2, ma2)
+    compute(buf);
+    store_stage(buf ^ 1, r0, ma0);
+    __syncthreads();
+    buf ^= 1;
   }
+#undef SALUN_IG_LOAD
   if (g.part) {  // split reduction: raw fp32 tile, finished by k_splitk_finish
     float *dst = g.part + (size_t)blockIdx.z * g.M * g.Kout;
 #pragma unroll

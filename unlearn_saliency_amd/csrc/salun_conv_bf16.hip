@@ -678,6 +678,8 @@ SALUN_EXPORT int salun_conv2d_bf16_forward(const uint16_t *x, const uint16_t *wp
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
   if (OH < 1 || OW < 1 || (int64_t)N * H * W * C >= (int64_t(1) << 31) || (int64_t)N * OH * OW * K >= (int64_t(1) << 31))
     return SALUN_EINVAL;
+  // the staging addresses use 24-bit multiplies: pixel counts and channel counts below 2^24
+  if ((int64_t)N * H * W >= (1 << 24) || (int64_t)N * OH * OW >= (1 << 24) || C >= (1 << 24) || K >= (1 << 24)) return SALUN_EINVAL;
   IgArgs a{x, wp, bias, nbias, addend, y, N * OH * OW, H, W, C, OH, OW, K, R, stride, pad, 1, K, C, nullptr, 0};
   return dispatch_igemm<false>(a, ws, ws_bytes, salun_hip_stream(stream));
 }
@@ -691,6 +693,8 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_data(const uint16_t *dy, const uint1
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
   if (OH < 1 || OW < 1 || (int64_t)N * H * W * C >= (int64_t(1) << 31) || (int64_t)N * OH * OW * K >= (int64_t(1) << 31))
     return SALUN_EINVAL;
+  // the staging addresses use 24-bit multiplies: pixel counts and channel counts below 2^24
+  if ((int64_t)N * H * W >= (1 << 24) || (int64_t)N * OH * OW >= (1 << 24) || C >= (1 << 24) || K >= (1 << 24)) return SALUN_EINVAL;
   // walk dX's pixels; the source is dY (zero-upsampled by `stride`), padding R-1-pad, taps flipped in the weight read
   IgArgs a{dy, wp, nullptr, nullptr, addend, dx, N * H * W, OH, OW, K, H, W, C, R, 1, R - 1 - pad, stride, K, C, nullptr, 0};
   return dispatch_igemm<true>(a, ws, ws_bytes, salun_hip_stream(stream));

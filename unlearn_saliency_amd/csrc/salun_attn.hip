@@ -211,6 +211,8 @@ __global__ __launch_bounds__(256) void attn_fwd(const AttnArgs g) {
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[j], s[sub], 0, 0, 0);
       }
     }
+    // softmax bookkeeping on the RAW scores (the scale c > 0 commutes with max; it enters through one fma per
+    // element: p = exp2(s*c - m)), five VALU operations per score instead of seven
     float mx = -INFINITY;
     if ((kt + 1) * KT > g.Nk) {  // ragged last tile (wave-uniform): keys past the end score -inf
       const int key0 = kt * KT + 4 * half;
@@ -219,21 +221,18 @@ __global__ __launch_bounds__(256) void attn_fwd(const AttnArgs g) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           const int key = key0 + sub * 32 + (v & 3) + 8 * (v >> 2);
-          const float x = key < g.Nk ? s[sub][v] * c : -INFINITY;
-          s[sub][v] = x;
-          mx = fmaxf(mx, x);
+          if (key >= g.Nk) s[sub][v] = -INFINITY;
+          mx = fmaxf(mx, s[sub][v]);
         }
     } else {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          s[sub][v] *= c;
-          mx = fmaxf(mx, s[sub][v]);
-        }
+        for (int v = 0; v < 16; ++v) mx = fmaxf(mx, s[sub][v]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
     const float m_new = fmaxf(m, mx);  // finite: every tile holds at least one valid key
+    const bool grew = m_new > m;
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     m = m_new;
     float ps = 0.f;
@@ -242,15 +241,19 @@ __global__ __launch_bounds__(256) void attn_fwd(const AttnArgs g) {
     for (int sub = 0; sub < 2; ++sub) {
       float p[16];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) { p[v] = __builtin_amdgcn_exp2f(s[sub][v] - m_new); ps += p[v]; }
+      for (int v = 0; v < 16; ++v) { p[v] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][v], c, -m_new)); ps += p[v]; }
       pf[sub][0] = pack_operand(p);
       pf[sub][1] = pack_operand(p + 8);
     }
     l = l * alpha + ps;
+    // the running maximum settles after the first tiles: rescale O^T only when some lane's maximum grew (wave-uniform)
+    const bool rescale = __builtin_amdgcn_ballot_w64(grew) != 0;
 #pragma unroll
     for (int t = 0; t < G::NT; ++t) {
+      if (rescale) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[t][v] *= alpha;
+        for (int v = 0; v < 16; ++v) acc[t][v] *= alpha;
+      }
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq(const AttnArgs g) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int key = key0 + sub * 32 + (v & 3) + 8 * (v >> 2);
-        const float p = key < g.Nk ? __builtin_amdgcn_exp2f(s[v] * c - L) : 0.f;
+        const float p = key < g.Nk ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[v], c, -L)) : 0.f;
         ds[v] = p * (dp[v] - Dq) * g.scale;
       }
       const bf16x8 d0 = pack_operand(ds), d1 = pack_operand(ds + 8);
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv(const AttnArgs g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int v = 4 * a + e;
-        p[v] = __builtin_amdgcn_exp2f(s[v] * c - lv[e]);
+        p[v] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[v], c, -lv[e]));
         ds[v] = p[v] * (dp[v] - dvv[e]) * g.scale;
       }
     }

@@ -49,3 +49,41 @@ def test_tiny_config_is_inside_the_bf16_kernels_domain():
     from unlearn_saliency_amd.conv_bf16 import use_salun_convs_bf16
     m = UNetModel(**sd_tiny_config())
     assert use_salun_convs_bf16(m) >= 8
+
+
+def test_bf16_kernels_refuse_host_tensors_loudly():
+    """No CPU path behind K11-K14: host tensors are an error, not a fallback."""
+    import pytest
+    from unlearn_saliency_amd import norm, ops
+    x = torch.randn(1, 8, 8, 32).to(torch.bfloat16)
+    wp = torch.zeros(32, 9, 32, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv2d_bf16_forward(x, wp, 3, 1, 1)
+    q = torch.randn(1, 16, 2, 40).to(torch.bfloat16)
+    with pytest.raises(TypeError, match="device tensor"):
+        ops.attention(q, q, q, 40 ** -0.5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layer_norm_bf16(torch.randn(4, 32).to(torch.bfloat16), torch.nn.LayerNorm(32))
+    # a bf16 host tensor through the GroupNorm dispatcher takes the library ops (is_cuda gate), it never reaches K12
+    gn = torch.nn.GroupNorm(4, 32)
+    y = norm.fused_gn_act(torch.randn(2, 32, 4, 4), gn, silu=True)
+    assert y.shape == (2, 32, 4, 4)
+
+
+def test_attention_view_contract():
+    """[B, tokens, H, D] views: heads must be adjacent runs of D contiguous channels (checked before any launch)."""
+    import pytest
+    from unlearn_saliency_amd import ops
+
+    class FakeCuda(torch.Tensor):
+        @property
+        def is_cuda(self):
+            return True
+
+    t = torch.randn(2, 6, 4, 8).to(torch.bfloat16)
+    bad = t.transpose(1, 2).as_subclass(FakeCuda)  # [B, H, tokens, D]: head stride is not D
+    with pytest.raises(ValueError, match="adjacent runs"):
+        ops._tok_view(bad, "q")
+    ok = t.as_subclass(FakeCuda)
+    ptr, bs, ld = ops._tok_view(ok, "q")
+    assert bs.value == 6 * 4 * 8 and ld.value == 4 * 8

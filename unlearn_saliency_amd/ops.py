@@ -318,6 +318,7 @@ def conv2d_bf16_forward(x: torch.Tensor, wp: torch.Tensor, R: int, stride: int, 
     N, H, W, C = x.shape
     K = wp.shape[0]
     OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    _dev(x, torch.bfloat16, "x")  # device / dtype / layout errors before anything touches the device
     y = torch.empty((N, OH, OW, K), dtype=torch.bfloat16, device=x.device)
     ws = workspace(_lib.lib().salun_conv2d_bf16_data_workspace_bytes(N, H, W, C, K, R, stride, pad), x.device)
     check(_lib.lib().salun_conv2d_bf16_forward(_dev(x, torch.bfloat16, "x"), _dev(wp, torch.bfloat16, "wp"),
@@ -333,6 +334,7 @@ def conv2d_bf16_backward_data(dy: torch.Tensor, wp: torch.Tensor, x_shape, R: in
                               addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     N, H, W, C = x_shape
     K = wp.shape[0]
+    _dev(dy, torch.bfloat16, "dy")
     dx = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
     ws = workspace(_lib.lib().salun_conv2d_bf16_data_workspace_bytes(N, H, W, C, K, R, stride, pad), dy.device)
     check(_lib.lib().salun_conv2d_bf16_backward_data(_dev(dy, torch.bfloat16, "dy"), _dev(wp, torch.bfloat16, "wp"),

@@ -202,15 +202,17 @@ __global__ __launch_bounds__(256) void attn_fwd(const AttnArgs g) {
     // ---- S^T for the 64 keys of the tile: two 32-key MFMA tiles, 16 keys of each per lane
     f32x16 s[2];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int v = 0; v < 16; ++v) s[sub][v] = 0.f;
+    // consecutive MFMAs alternate between independent accumulators (a dependent chain would wait out each result)
 #pragma unroll
-      for (int j = 0; j < G::NJ; ++j) {
+    for (int j = 0; j < G::NJ; ++j)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(k_rm + a_off + sub * 32 * G::ROWB + j * 32);
         s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[j], s[sub], 0, 0, 0);
       }
-    }
     // softmax bookkeeping on the RAW scores (the scale c > 0 commutes with max; it enters through one fma per
     // element: p = exp2(s*c - m)), five VALU operations per score instead of seven
     float mx = -INFINITY;
@@ -248,20 +250,21 @@ __global__ __launch_bounds__(256) void attn_fwd(const AttnArgs g) {
     l = l * alpha + ps;
     // the running maximum settles after the first tiles: rescale O^T only when some lane's maximum grew (wave-uniform)
     const bool rescale = __builtin_amdgcn_ballot_w64(grew) != 0;
+    if (rescale) {
 #pragma unroll
-    for (int t = 0; t < G::NT; ++t) {
-      if (rescale) {
+      for (int t = 0; t < G::NT; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] *= alpha;
-      }
+    }
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t) {  // channel tiles innermost: independent accumulators back to back
           const bf16x8 a = tr_operand(v_tr, tr_off + t * (KT * 64) + (sub * 32 + 16 * e) * 64, 8 * 64);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[sub][e], acc[t], 0, 0, 0);
         }
-    }
     __syncthreads();
     if (kt + 1 < ntiles) {
       tk.store(k_rm, nullptr, tid);

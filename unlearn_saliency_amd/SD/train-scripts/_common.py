@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 def add_batch_source_flags(parser):
     parser.add_argument("--latents", type=str, default=None, help="file with pre-encoded forget / remain batches")
     parser.add_argument("--synthetic", type=int, default=0, help="use this many synthetic batches instead")
-    parser.add_argument("--bf16", action="store_true", help="run the U-Net under bf16 autocast (fp32 master weights)")
+    parser.add_argument("--bf16", action="store_true", help="bf16 configuration: bf16 NHWC MFMA convolutions, GroupNorm, attention, LayerNorm / GEGLU kernels (K11-K14), fp32 master weights")
 
 
 def device_of(arg: str) -> str:

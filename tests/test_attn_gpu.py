@@ -60,3 +60,14 @@ def test_strided_views_of_a_fused_projection():
     o, _ = ops.attn_forward(*parts, D ** -0.5, need_lse=False)
     oc, _ = ops.attn_forward(*[p.contiguous() for p in parts], D ** -0.5, need_lse=False)
     assert torch.equal(o, oc)
+
+
+@pytest.mark.parametrize("scale", [0.0, -0.125, float("inf"), float("nan")])
+def test_non_positive_or_non_finite_scale_is_refused(scale):
+    """the kernels take the row maximum on the raw scores and apply scale*log2(e) afterwards, which is only
+    monotone for a positive finite scale; anything else must be an error, not inf / NaN outputs."""
+    from unlearn_saliency_amd import ops
+    q = torch.randn(1, 16, 2, 40, device="cuda").to(torch.bfloat16)
+    with pytest.raises(Exception) as ei:
+        ops.attention(q, q, q, scale)
+    assert "EINVAL" in str(ei.value) or "-22" in str(ei.value) or "invalid" in str(ei.value).lower()

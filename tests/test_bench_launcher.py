@@ -43,3 +43,29 @@ def test_gpus_2_without_two_devices_fails_loudly():
 def test_world_size_must_match_gpus_flag():
     r = _run(["--gpus", "1", "--selftest_launcher"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "disagrees" in (r.stderr + r.stdout)
+
+
+def _json_line(r):
+    assert r.returncode == 0, r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_class_forget_workload_shards_over_two_ranks():
+    """BASELINE configs[2] under the launcher: `bench.py --gpus 2 --forget class` — both ranks mark the same 4,500
+    samples of class 0 and their shards partition every global batch (gloo on the CPU; the device step itself is the
+    single-GPU path of tests/test_classwise_gpu.py plus the all-reduce of tests/test_dist_gloo.py)."""
+    out = _json_line(_run(["--gpus", "2", "--forget", "class", "--selftest_workload"], {"OMP_NUM_THREADS": "1"}))
+    assert out["n_gpus"] == 2 and out["forget"] == "class" and out["forget_classes"] == [0]
+    assert out["forget_samples"] == 4500 and out["retain_samples"] == 40500
+    assert out["global_batch"] == 512 and out["forget_batches"] == 9     # weak scaling: 256 per rank
+    assert out["shards_partition_every_batch"] and out["shard_imbalance_max"] <= 1
+    assert sum(out["tail_batch"]) == 4500 - 8 * 512
+
+
+def test_strong_scaling_keeps_the_reference_global_batch():
+    out = _json_line(_run(["--gpus", "2", "--scaling", "strong", "--selftest_workload"], {"OMP_NUM_THREADS": "1"}))
+    assert out["forget"] == "random" and len(out["forget_classes"]) == 10
+    assert out["global_batch"] == 256 and out["forget_batches"] == 18   # the reference's 18 forget batches per epoch
+    assert out["shards_partition_every_batch"] and out["tail_batch"] == [74, 74]

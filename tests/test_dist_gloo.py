@@ -206,3 +206,53 @@ def test_bucketed_overlapped_allreduce_equals_full_batch_gradient(tmp_path):
     nn.CrossEntropyLoss()(model(torch.from_numpy(x)), torch.from_numpy(y)).backward()
     g = np.concatenate([p.grad.reshape(-1).numpy() for p in model.parameters()])
     assert np.allclose(g0, g, rtol=1e-5, atol=1e-7)
+
+
+# -------------------------------------------------- a rank with an EMPTY shard (tail batch smaller than the world)
+def _empty_shard(rank, out_dir):
+    """a rank whose shard of a ragged tail batch is empty runs no backward; its buckets must still pair up
+    with the other rank's hook-launched slices (different sizes): same order, or the all-reduces mismatch."""
+    from fixtures import TinyCNN, tiny_batches, tiny_state
+    from unlearn_saliency_amd import dist as sdist
+    from unlearn_saliency_amd.flat import FlatArena
+    model = TinyCNN()
+    model.load_state_dict(tiny_state(21))
+    model.eval()
+    arena = FlatArena.from_module(model, device="cpu")
+    red = sdist.BucketedGradReducer(arena, num_buckets=3)
+    sizes = {hi - lo for lo, hi in red.bounds}
+    assert len(sizes) > 1, "the case needs slices of different sizes"
+    x, y = tiny_batches(1, 16, 700)[0]
+    for first_step_empty in (False, True):
+        if first_step_empty:
+            red._seen_order = None  # as on the very first step: no complete backward seen yet
+        else:  # one complete step on both ranks first (records the hooks' launch order)
+            lo, hi = sdist.balanced_slice(16)
+            arena.zero_grad()
+            nn.CrossEntropyLoss()(model(torch.from_numpy(x[lo:hi])), torch.from_numpy(y[lo:hi])).backward()
+            red.finish()
+        # tail batch of ONE sample: balanced_slice gives rank 0 nothing, rank 1 the sample
+        lo, hi = sdist.balanced_slice(1)
+        assert (hi - lo) == (0 if rank == 0 else 1)
+        arena.zero_grad()
+        if hi > lo:
+            w = (hi - lo) * WORLD / 1.0
+            (nn.CrossEntropyLoss()(model(torch.from_numpy(x[:1])), torch.from_numpy(y[:1])) * w).backward()
+        red.finish()
+        np.save(os.path.join(out_dir, f"tail_{int(first_step_empty)}_{rank}.npy"), arena.grads.numpy().copy())
+
+
+def test_empty_shard_rank_issues_its_buckets_in_the_hooks_order(tmp_path):
+    _run("_empty_shard", tmp_path)
+    sys.path.insert(0, ROOT)
+    from fixtures import TinyCNN, tiny_batches, tiny_state
+    model = TinyCNN()
+    model.load_state_dict(tiny_state(21))
+    model.eval()
+    x, y = tiny_batches(1, 16, 700)[0]
+    nn.CrossEntropyLoss()(model(torch.from_numpy(x[:1])), torch.from_numpy(y[:1])).backward()
+    g = np.concatenate([p.grad.reshape(-1).numpy() for p in model.parameters()])
+    for tag in (0, 1):
+        g0, g1 = np.load(tmp_path / f"tail_{tag}_0.npy"), np.load(tmp_path / f"tail_{tag}_1.npy")
+        assert np.array_equal(g0, g1)
+        assert np.allclose(g0, g, rtol=1e-6, atol=1e-8)  # AVG over ranks of (2 x sample gradient, 0) = the batch mean

@@ -211,3 +211,32 @@ def test_validate_and_mia_on_the_device_match_the_reference(golden_dir):
     cpu_test = importlib.import_module("test_eval_vs_golden")
     assert hasattr(cpu_test, "run_eval"), "tests/test_eval_vs_golden.py exposes run_eval(device)"
     cpu_test.run_eval(golden_dir, "cuda")
+
+
+def test_a_failed_select_poisons_the_weights_instead_of_resetting_them():
+    """when the select fails (the full scan's grid barrier timed out), `salun_mask_topk_thresholds` exports
+    NaN and `salun_soft_threshold_step` must spread it — a plain comparison against NaN would silently write p0
+    everywhere (every weight reset), the worst possible quiet outcome."""
+    import ctypes
+    from unlearn_saliency_amd import _lib, ops
+    n = 10_000
+    p0 = torch.randn(n, device="cuda")
+    p = p0 + 0.01 * torch.randn(n, device="cuda")
+    tau = torch.full((1,), float("nan"), device="cuda")
+    ops.check(_lib.lib().salun_soft_threshold_step(ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(p0.data_ptr()),
+                                                   ctypes.c_void_p(tau.data_ptr()), ctypes.c_int64(n), ops._stream()),
+              "salun_soft_threshold_step")
+    assert bool(torch.isnan(p).all())
+    # and the healthy path: a finite threshold behaves as before
+    p = p0 + 0.01 * torch.randn(n, device="cuda")
+    t = ops.proximal_step(p, p0, n // 2)
+    assert bool(torch.isfinite(p).all()) and float(t) > 0 and int((p == p0).sum()) >= n // 2
+
+
+def test_mask_topk_check_reports_a_healthy_select():
+    from unlearn_saliency_amd import ops
+    acc = torch.randn(50_000, device="cuda")
+    m = ops.mask_topk(acc, [25_000], check=True)[0]                      # single-read route
+    assert int(m.sum()) == 25_000 and ops.mask_topk_status(acc.device) == (1, 0)
+    m = ops.mask_topk(acc[:5000], [2500], check=True)[0]                 # n < 8192: the (cooperative) full scan
+    assert int(m.sum()) == 2500 and ops.mask_topk_status(acc.device) == (2, 0)

@@ -87,3 +87,35 @@ def test_attention_view_contract():
     ok = t.as_subclass(FakeCuda)
     ptr, bs, ld = ops._tok_view(ok, "q")
     assert bs.value == 6 * 4 * 8 and ld.value == 4 * 8
+
+
+def test_pack_cache_sees_in_place_writes_on_the_flat_arena():
+    """FlatArena binds parameters with `p.data = flat[o:o+k].view(...)`; a torch write on `arena.params`
+    (a model reset, a copy from a checkpoint vector) does not bump the parameter's own version counter — the pack cache
+    must key on the flat vector's counter as well, or forward / backward-data keep a stale bf16 weight image."""
+    from unlearn_saliency_amd import ops
+    from unlearn_saliency_amd.conv_bf16 import SalunConv2dBF16
+    from unlearn_saliency_amd.flat import FlatArena
+    calls = []
+    real = ops.conv2d_bf16_pack
+    ops.conv2d_bf16_pack = lambda w, out=None: calls.append(1) or torch.zeros(1)
+    try:
+        c = torch.nn.Conv2d(32, 32, 3, padding=1)
+        c.__class__ = SalunConv2dBF16
+        arena = FlatArena.from_module(c, device="cpu")
+        c.packed_weight(); c.packed_weight()
+        assert len(calls) == 1
+        v = c.weight._version
+        with torch.no_grad():
+            arena.params.mul_(0.5)                  # in place on the flat vector
+        assert c.weight._version == v               # ... which the parameter's own counter does not see
+        c.packed_weight()
+        assert len(calls) == 2
+        with torch.no_grad():
+            arena.params[3:7].zero_()               # a slice shares the flat vector's counter
+        c.packed_weight()
+        assert len(calls) == 3
+        c.packed_weight()
+        assert len(calls) == 3
+    finally:
+        ops.conv2d_bf16_pack = real

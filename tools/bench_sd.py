@@ -1,5 +1,12 @@
-"""SD-v1 U-Net SalUn benchmark on ONE GPU (BASELINE.json configs: SD nudity; synthetic latents / contexts,
-randomly initialised 859,520,964-parameter U-Net of the v1-inference shape, batch 8 at 64x64 latents):
+"""SD-v1 U-Net SalUn benchmark (BASELINE.json configs[4]: SD nudity; synthetic latents / contexts, randomly
+initialised 859,520,964-parameter U-Net of the v1-inference shape, batch 8 per GPU at 64x64 latents).
+
+    python bench.py --workload sd --gpus N --steps K --warmup W     (driver-reachable; launches N ranks, bf16)
+    python tools/bench_sd.py [--steps K] [--warmup W] [--bf16] [--library_conv]             (one GPU)
+
+Rank-aware (reads RANK / WORLD_SIZE through dist.init_from_env): every rank draws its own batch of 8 (the reference
+script is single-GPU; under data parallel the global batch is 8 x N, weak scaling), Phase A sums the flat accumulator
+over ranks once, Phase B averages the flat gradient per step in buckets overlapped with backward.
 
   Phase A  generate_nsfw_mask body: per batch 2 U-Net forwards + backward, flat accumulate, then the global
            top-k (ratio 0.5) over N_S = 859.5 M saliencies
@@ -16,20 +23,29 @@ NS = 859_520_964
 FWD_TFLOP_PER_SAMPLE = 0.803  # SURVEY.md §8 D2 (FlopCounterMode on the reference module)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--scaling", default="weak", choices=["weak"], help="batch 8 per GPU cannot be split further")
+    ap.add_argument("--no_cpu_baseline", action="store_true", help="accepted for symmetry: this workload has none")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mask_batches", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--library_conv", action="store_true")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+    from unlearn_saliency_amd import dist as sdist
     from unlearn_saliency_amd import ops
     from unlearn_saliency_amd.SD import train_scripts as TS
     from unlearn_saliency_amd.SD.ldm_lite import LatentDiffusionLite
-    dev = torch.device("cuda", 0)
-    torch.manual_seed(0)
+    rank, local_rank, world = sdist.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} disagrees with WORLD_SIZE={world} (launch through bench.py --workload sd)")
+    rccl_ranks = sdist.counted_ranks()
+    assert rccl_ranks == world, (rccl_ranks, world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(0)  # identical initial weights on every rank (replicas stay bit-identical: no broadcast)
     torch.backends.cudnn.benchmark = True
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(sys.stderr):
@@ -46,6 +62,7 @@ def main():
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0
     B = a.batch
+    torch.manual_seed(1000 + rank)  # from here on every rank draws its OWN latents / noise / timesteps
     mk = lambda *s: torch.randn(*s, device=dev)
     # ---- Phase A
     batches = [(mk(B, 4, 64, 64), mk(B, 77, 768), mk(B, 77, 768)) for _ in range(a.mask_batches)]
@@ -61,7 +78,7 @@ def main():
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
-    m = ops.mask_topk(acc, [int(NS * 0.5)])[0]
+    m = ops.mask_topk(acc, [int(NS * 0.5)], check=True)[0]
     ev[1].record()
     torch.cuda.synchronize()
     topk_ms = ev[0].elapsed_time(ev[1])
@@ -101,21 +118,37 @@ def main():
     run.opt.set_mask(m)
     run(a.warmup)
     torch.cuda.synchronize()
+    sdist.barrier()
     t0 = time.perf_counter()
     tail = run(a.steps)
     torch.cuda.synchronize()
+    sdist.barrier()
     dt = (time.perf_counter() - t0) / a.steps
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
     tail_ms = sum(e0.elapsed_time(e1) for e0, e1 in tail) / len(tail)
     # step = 3 forwards + 2 backwards (2x forward each) + 2 recomputed forwards (activation checkpointing)
     tflop = B * FWD_TFLOP_PER_SAMPLE * (3 + 4 + 2)
     out = {
         "metric": "sd_unlearn_steps_per_sec (SD-v1 U-Net nsfw_removal body, batch 8, 64x64 latents)",
-        "value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "steps": a.steps, "warmup": a.warmup,
+        "value": world / dt, "unit": "steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+        "backend": (torch.distributed.get_backend() if sdist.is_dist() else "single-process"),
+        "ms_per_step": dt * 1e3, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "config": {"workload": "Stable Diffusion v1 LDM U-Net (859,520,964 params), nsfw_removal loop body "
+                               "(SD/train-scripts/nsfw_removal.py:33-175): remain pass + forget pass + pseudo pass, "
+                               "SalUn mask ratio 0.5, masked Adam 1e-5, 64x64 latents, batch 8 per GPU "
+                               "(BASELINE.json configs[4])",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "dtype": "bf16 autocast (fp32 master weights / Adam)" if a.bf16 else "f32", "data": "synthetic",
         "params": NS, "salun_mfma_convs": n_salun, "library_conv_calls": sconv.library_conv_calls(), "init_sec": t_init,
         "mask_gen": {"batches": a.mask_batches, "saliency_sec": t_mask, "topk_ms_at_NS": topk_ms,
                      "topk_GBps_algorithmic": 5.0 * NS / (topk_ms * 1e-3) / 1e9},
-        "roofline": {"kernel": "salun_masked_adam_step @ N_S", "bound": "hbm", "algorithmic_bytes": 29 * NS,
+        "roofline": {"kernel": "salun_masked_adam_step @ N_S" + ("" if not sdist.collectives_on() else
+                                                                  " (+ gradient-bucket join)"),
+                     "traffic": None, "bound": "hbm", "algorithmic_bytes": 29 * NS,
                      "mean_launch_ms": tail_ms, "achieved": 29.0 * NS / (tail_ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": 29.0 * NS / (tail_ms * 1e-3) / 1e9 / 8000.0},
         "fwd_bwd": {"tflop_per_step": tflop, "achieved_TFLOPs": tflop / dt,
@@ -127,7 +160,11 @@ def main():
                     "layer_norm_geglu": "K14 bf16 tokens" if a.bf16 else "library"},
         "hbm_peak_alloc_GB": torch.cuda.max_memory_allocated() / 1e9,
     }
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sdist.barrier()
+    if sdist.is_dist():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -74,7 +74,7 @@ def masks_from_saliency(acc: torch.Tensor, ratios) -> "OrderedDict[float, torch.
     out: "OrderedDict[float, torch.Tensor]" = OrderedDict()
     for s in range(0, len(ratios), 16):  # SALUN_MAX_THRESHOLDS per call
         chunk = ratios[s:s + 16]
-        masks = ops.mask_topk(acc, [int(n * r) for r in chunk])
+        masks = ops.mask_topk(acc, [int(n * r) for r in chunk], check=True)  # raises instead of returning garbage
         out.update(zip(chunk, masks))
     return out
 

@@ -189,7 +189,7 @@ class Diffusion(object):
         t0 = time.time()
         acc = self.accumulate_saliency(model, forget_loader, arena)
         threshold_list = [0.5]  # reference :1006
-        masks = ops.mask_topk(acc, [int(arena.n * r) for r in threshold_list])
+        masks = ops.mask_topk(acc, [int(arena.n * r) for r in threshold_list], check=True)
         torch.cuda.synchronize()
         logging.info(f"saliency + top-k: {time.time() - t0:.2f}s")
         mask_path = os.path.join(getattr(args, "mask_dir", "results/cifar10/mask"), str(args.label_to_forget))

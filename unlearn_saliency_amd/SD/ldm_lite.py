@@ -35,6 +35,9 @@ class LatentDiffusionLite(nn.Module):
         self.first_stage_key, self.cond_stage_key = "jpg", "txt"
         self.first_stage, self.cond_stage, self.scale_factor = first_stage, cond_stage, scale_factor
         self.bf16 = bf16
+        # parameters of the frozen stages a full LatentDiffusion would carry next to the U-Net (0 here: they are not
+        # instantiated); `setup_model` sets the SD-v1 count — only the proximal step's global ranking depends on it
+        self.frozen_param_count = 0
         # "linear" schedule of the LDM code base: linspace(sqrt(start), sqrt(end))**2 in float64 (util.py:24-30)
         betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=np.float64) ** 2
         ac = np.cumprod(1.0 - betas, axis=0)

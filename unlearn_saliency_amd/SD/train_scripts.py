@@ -31,6 +31,12 @@ from .unet import V1_UNET_CONFIG
 
 UNET_PREFIX = "model.diffusion_model."
 
+# Parameters of the frozen stages of the reference's SD-v1 LatentDiffusion: AutoencoderKL (ddconfig of
+# configs/stable-diffusion/v1-inference.yaml: 83,653,863) + CLIP ViT-L/14 text model (123,060,480).  They never move,
+# but the reference's proximal step ranks |theta - theta_0| over `model.parameters()` of the WHOLE LatentDiffusion
+# (proximal_gradient.py:66-72,141-167), so their zeros occupy the lowest ranks of its top-k.
+SD_V1_FROZEN_PARAMS = 83_653_863 + 123_060_480
+
 
 def setup_model(config_path, ckpt_path, device, bf16=False) -> LatentDiffusionLite:
     """YAML (`model.params.unet_config.params`, e.g. configs/stable-diffusion/v1-inference.yaml) + optional CompVis
@@ -41,6 +47,8 @@ def setup_model(config_path, ckpt_path, device, bf16=False) -> LatentDiffusionLi
             params = yaml.safe_load(f)["model"]["params"]["unet_config"]["params"]
         cfg.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in params.items()})
     model = LatentDiffusionLite(cfg, bf16=bf16).to(device)
+    if all(cfg.get(k) == V1_UNET_CONFIG.get(k) for k in ("model_channels", "channel_mult", "context_dim")):
+        model.frozen_param_count = SD_V1_FROZEN_PARAMS  # the v1 first stage + text encoder (see above)
     if ckpt_path and os.path.exists(ckpt_path):
         sd = torch.load(ckpt_path, map_location=device, weights_only=False)
         sd = sd.get("state_dict", sd)
@@ -78,7 +86,7 @@ def _saliency_mask(model, batches, c_guidance, mask_path, ratio=0.5):
         loss.backward()
         ops.saliency_accumulate(acc, arena.grads, 1.0)
     sdist.all_reduce_sum_(acc)
-    mask = ops.mask_topk(acc, [int(arena.n * ratio)])[0]
+    mask = ops.mask_topk(acc, [int(arena.n * ratio)], check=True)[0]  # raises instead of saving a garbage mask
     if mask_path and sdist.rank() == 0:
         os.makedirs(mask_path, exist_ok=True)
         torch.save(arena.unpack_mask(mask), os.path.join(mask_path, f"with_{str(ratio)}.pt"))
@@ -127,6 +135,9 @@ def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_me
     the flat arena, K9)."""
     arena = _unet_arena(model)
     init_params = arena.params.clone() if proximal_ratio is not None else None
+    # the reference ranks over the whole LatentDiffusion: U-Net + the frozen first stage and text encoder
+    n_frozen = int(getattr(model, "frozen_param_count", 0)) if proximal_ratio is not None else 0
+    n_total = arena.n + n_frozen
     steps_per_epoch = len(forget_dl) + len(remain_dl) if proximal_ratio is not None else 0  # proximal_gradient.py:73
     total_steps = epochs * steps_per_epoch
     opt = FusedMaskedAdam(arena, lr=lr)  # torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no clipping
@@ -161,11 +172,14 @@ def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_me
             losses.append(loss.detach())
             if proximal_ratio is not None:
                 # proximal_gradient.py:141-176: ratio of weights pulled back onto theta_0, linearly decaying schedule
-                ratio = int(proximal_ratio * ((total_steps - (epoch * steps_per_epoch + i + 1)) / total_steps * arena.n))
-                if ratio >= 1:
-                    ops.proximal_step(arena.params, init_params, ratio)
-                else:
+                ratio = int(proximal_ratio * ((total_steps - (epoch * steps_per_epoch + i + 1)) / total_steps * n_total))
+                if ratio < 1:
                     raise IndexError("index -1 is out of bounds for dimension 0 with size 0")  # topk(.., 0)[0][-1]
+                # the n_frozen zeros of the frozen stages are the smallest |theta - theta_0|: the ratio-th smallest
+                # over the whole model is 0 while ratio <= n_frozen (soft-threshold by 0 = identity), else the
+                # (ratio - n_frozen)-th smallest over the U-Net
+                if ratio > n_frozen:
+                    ops.proximal_step(arena.params, init_params, ratio - n_frozen)
     model.eval()
     return [float(v) for v in torch.stack(losses).cpu()] if losses else []
 

@@ -74,7 +74,7 @@ class _ConvFn(torch.autograd.Function):
             dst = gradsink.sink(w) if ctx.native else None
             # the weight gradient goes straight into .grad (gradsink): nothing on the main stream consumes it before
             # the end of the backward pass, so it can run on the side stream next to backward-data (resblock.py)
-            overlap = (dst is not None and resblock.OVERLAP_WGRAD and sdist.world_size() == 1)
+            overlap = (dst is not None and resblock.OVERLAP_WGRAD and not sdist.collectives_on())
             if overlap:
                 main, side = torch.cuda.current_stream(dy.device), resblock._side_stream(dy.device)
                 side.wait_stream(main)

@@ -50,7 +50,10 @@ class _ConvBF16Fn(torch.autograd.Function):
         dx = dw = db = dnb = dadd = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dst = gradsink.sink(w)
-            bdst = gradsink.sink(mod.bias) if ctx.has_bias else None
+            # the kernel has ONE accumulate flag for dw and db: without a weight sink it overwrites both outputs, so
+            # the bias gradient must not target bias.grad then (it would be overwritten, not accumulated) — it goes
+            # through autograd like dw; with a weight sink but no bias sink, db accumulates into fresh zeros
+            bdst = gradsink.sink(mod.bias) if (ctx.has_bias and dst is not None) else None
             if ctx.has_bias and bdst is None:
                 bdst = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
                 db = bdst
@@ -76,7 +79,11 @@ class SalunConv2dBF16(nn.Conv2d):
 
     def packed_weight(self) -> torch.Tensor:
         w = self.weight
-        key = (ops.PARAM_EPOCH[0], w._version, w.data_ptr())
+        # PARAM_EPOCH: bumped by every kernel that rewrites parameters through raw pointers; w._version: torch writes
+        # on the parameter itself; the flat arena's version: torch writes on `arena.params` (or any slice of it) do
+        # NOT bump the parameter's own counter — `p.data = view` gave it a separate one (flat.py)
+        flat = getattr(w, "_salun_flat", None)
+        key = (ops.PARAM_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
         if self._pack is None or self._pack_key != key or self._pack.device != w.device:
             self._pack = ops.conv2d_bf16_pack(w.detach(), self._pack if self._pack is not None and self._pack.device == w.device else None)
             self._pack_key = key

@@ -529,6 +529,9 @@ SALUN_EXPORT int salun_attn_forward(const uint16_t *q, const uint16_t *k, const 
   if (!q || !k || !v || !o || !attn_ok(B, H, Nq, Nk, D)) return SALUN_EINVAL;
   if (!salun_aligned16(q) || !salun_aligned16(k) || !salun_aligned16(v) || !salun_aligned16(o)) return SALUN_EINVAL;
   if ((q_ld | k_ld | v_ld | o_ld) % 8 || (q_bs | k_bs | v_bs | o_bs) % 8) return SALUN_EINVAL;
+  // the kernels take the running maximum on the RAW scores and multiply by scale*log2(e) afterwards: that is only
+  // monotone for a positive, finite scale (every attention of the three models uses 1/sqrt(d))
+  if (!(scale > 0.0) || !(scale < 1e30)) return SALUN_EINVAL;
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
   a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
@@ -557,6 +560,7 @@ SALUN_EXPORT int salun_attn_backward(const uint16_t *q, const uint16_t *k, const
       !salun_aligned16(dq) || !salun_aligned16(dk) || !salun_aligned16(dv))
     return SALUN_EINVAL;
   if ((q_ld | k_ld | v_ld | o_ld | do_ld) % 8 || (q_bs | k_bs | v_bs | o_bs | do_bs) % 8) return SALUN_EINVAL;
+  if (!(scale > 0.0) || !(scale < 1e30)) return SALUN_EINVAL;  // see salun_attn_forward
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = const_cast<uint16_t *>(o); a.d_o = d_o; a.lse = const_cast<float *>(lse); a.dsum = dsum;
   a.dq = dq; a.dk = dk; a.dv = dv;

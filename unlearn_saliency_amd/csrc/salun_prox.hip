@@ -18,8 +18,12 @@ constexpr int EWC_MAX_BLOCKS = 2048;
 __device__ __forceinline__ float4 ld4(const float *p, int64_t v) { return reinterpret_cast<const float4 *>(p)[v]; }
 __device__ __forceinline__ void st4(float *p, int64_t v, float4 x) { reinterpret_cast<float4 *>(p)[v] = x; }
 
+// A NaN threshold is the select's failure signal (salun_mask_topk_thresholds exports NaN when the full scan's grid
+// barrier timed out, or when the ranked element itself is NaN): the weights are poisoned with it so that the next
+// loss is NaN — never a silent "every weight reset to p0", which is what the comparisons below would give.
 __device__ __forceinline__ float soft(float p, float p0, float tau) {
   const float d = p - p0;
+  if (tau != tau) return tau;
   return d > tau ? p - tau : (d < -tau ? p + tau : p0);
 }
 

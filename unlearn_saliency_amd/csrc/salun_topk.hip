@@ -1168,7 +1168,8 @@ __global__ void k_export_tau(const TopkPub *pub, int nk, float *out) {
   if (j >= nk) return;
   const uint32_t mode = pub->mode[j];
   float v;
-  if (mode == MODE_NONE) v = __uint_as_float(0x7F800000u);        // +inf: nothing selected
+  if (pub->error) v = __uint_as_float(0x7FC00000u);                 // the select failed: NaN poisons every consumer
+  else if (mode == MODE_NONE) v = __uint_as_float(0x7F800000u);        // +inf: nothing selected
   else if (mode == MODE_ALL) v = -1.0f;                             // below every |x|
   else v = pub->tau[j] ? __uint_as_float(pub->tau[j] - 1u) : __uint_as_float(0x7FC00000u);
   out[j] = v;
@@ -1452,8 +1453,22 @@ SALUN_EXPORT int salun_mask_topk_ex(const float *acc, int64_t n, const int64_t *
     if (hipMemsetAsync(pub, 0, sizeof(TopkPub), st) != hipSuccess) return SALUN_EIO;
     if (hipMemsetAsync(&full->bar, 0, 8, st) != hipSuccess) return SALUN_EIO;
     const size_t lds_bytes = D0_BINS + sizeof(uint32_t) * (size_t)(nk < 2 ? 2 : nk) * 1024;
-    hipLaunchKernelGGL(k_fullscan, dim3(fullscan_grid(n)), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, kl, mp, pub, full,
-                       static_cast<const FastState *>(nullptr), tie, 1, (int)aligned, (int)maligned, (int)values_only);
+    // The kernel synchronises its workgroups with a software grid barrier, which needs all of them resident at once:
+    // a COOPERATIVE launch makes the runtime guarantee that (it waits for room instead of letting side-stream /
+    // RCCL kernels or another tenant hold back part of the grid).  If the runtime refuses the cooperative launch the
+    // plain launch below still works — its barrier is bounded and a time-out is reported (pub->error -> NaN
+    // thresholds, salun_mask_topk_status), never silent.
+    const FastState *no_fs = nullptr;
+    int always = 1, al = (int)aligned, mal = (int)maligned, vo = (int)values_only;
+    void *args[] = {(void *)&acc, (void *)&n, (void *)&kl, (void *)&mp, (void *)&pub, (void *)&full, (void *)&no_fs,
+                    (void *)&tie, (void *)&always, (void *)&al, (void *)&mal, (void *)&vo};
+    const int grid = fullscan_grid(n);
+    if (hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_fullscan), dim3(grid), dim3(SALUN_BLOCK), args,
+                                   (unsigned)lds_bytes, st) != hipSuccess) {
+      (void)hipGetLastError();
+      hipLaunchKernelGGL(k_fullscan, dim3(grid), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, kl, mp, pub, full, no_fs, tie,
+                         1, al, mal, vo);
+    }
     SALUN_LAUNCH_CHECK();
     return SALUN_OK;
   }

@@ -30,6 +30,18 @@ def rank() -> int:
     return dist.get_rank() if is_dist() else 0
 
 
+def force_collectives() -> bool:
+    """SALUN_FORCE_COLLECTIVES=1: create the process group and issue every collective of the data-parallel path even at
+    world size 1 — how the RCCL branch (`device_id=`, ReduceOp.AVG, the async gradient buckets and their stream
+    joins) is exercised on a single-GPU box (tests/test_rccl_ws1_gpu.py, `bench.py --force_collectives`)."""
+    return os.environ.get("SALUN_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
+def collectives_on() -> bool:
+    """True when gradients / accumulators must go through the process group: more than one rank, or forced."""
+    return is_dist() and (dist.get_world_size() > 1 or force_collectives())
+
+
 def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
     """Initialise from torchrun's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; no-op when single-process.
     Returns (rank, local_rank, world_size) and binds this process to its GPU."""
@@ -38,7 +50,7 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
     lrk = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(lrk % max(torch.cuda.device_count(), 1))
-    if ws > 1 and not is_dist():
+    if (ws > 1 or force_collectives()) and not is_dist():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -95,7 +107,7 @@ def launch_ranks(script: str, argv: list, nproc: int, require_devices: bool = Tr
 
 
 def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
-    if world_size() > 1:
+    if collectives_on():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
@@ -104,7 +116,7 @@ def all_reduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     """In-place mean over ranks.  RCCL reduces with AVG natively (no extra pass over the vector);
     gloo has no AVG, so SUM then scale."""
     ws = world_size()
-    if ws > 1:
+    if collectives_on():
         if dist.get_backend() == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG)
         else:
@@ -184,6 +196,8 @@ class BucketedGradReducer:
         self.arrived = [0] * len(self.bounds)
         self.launched = [False] * len(self.bounds)
         self.works = []
+        self._order = []        # bucket indices in the order this step launched them
+        self._seen_order = None  # launch order of the last complete backward (identical on every rank: same graph)
         self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
                          for i, p in enumerate(arena._params)]
 
@@ -200,21 +214,32 @@ class BucketedGradReducer:
         lo, hi = self.bounds[b]
         sl = self.arena.grads[lo:hi]
         self.launched[b] = True
+        self._order.append(b)
         if dist.get_backend() == "nccl":
             self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.AVG, async_op=True), None))
         else:
             self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True), sl))
 
     def finish(self):
-        for b in range(len(self.bounds)):
-            if not self.launched[b]:
-                self._launch(b)
+        # Buckets that no hook launched (unused parameters; a rank whose shard of a ragged tail batch is EMPTY runs no
+        # backward at all) must be issued in the order the OTHER ranks' hooks issue theirs, or the slices of
+        # different sizes pair up wrongly across ranks: the order of the last complete backward, else last bucket
+        # first (backward fills the flat gradient from its end).
+        hooked_all = all(self.launched)
+        if hooked_all:
+            self._seen_order = list(self._order)
+        else:
+            natural = self._seen_order or list(range(len(self.bounds) - 1, -1, -1))
+            for b in natural:
+                if not self.launched[b]:
+                    self._launch(b)
         ws = world_size()
         for work, needs_div in self.works:
             work.wait()
             if needs_div is not None:
                 needs_div.div_(ws)
         self.works.clear()
+        self._order = []
         self.arrived = [0] * len(self.bounds)
         self.launched = [False] * len(self.bounds)
 

@@ -49,6 +49,9 @@ class FlatArena:
             for p, o, k, shp in zip(self._params, self.offsets, self.numels, self.shapes):
                 self.params[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.params[o:o + k].view(shp)
+                # weight-image caches (conv_bf16.packed_weight) key on the flat vector's version counter: an in-place
+                # torch write on `arena.params` bumps that one, not the parameter's own
+                p._salun_flat = self.params
         self.attach_grads()
 
     @classmethod

@@ -69,11 +69,19 @@ def saliency_accumulate(acc: torch.Tensor, g: torch.Tensor, scale: float = 1.0,
 
 
 # ----------------------------------------------------------------------------- K2
+class TopkFailed(RuntimeError):
+    """The full-scan route's grid barrier timed out (its workgroups were not co-resident): the masks are garbage."""
+
+
 def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch.Tensor]] = None,
-              flags: int = 0) -> list[torch.Tensor]:
+              flags: int = 0, check: bool = False) -> list[torch.Tensor]:
     """One u8 0/1 mask per k: the k largest |acc| (ties: lowest flat index first).
     `flags`: _lib.SALUN_TOPK_* (FORCE_FULL_SCAN for A/B tests, VALUES_ONLY publishes the thresholds without
-    writing masks — returns [])."""
+    writing masks — returns []).
+    `check=True` reads the device-side status after the call (ONE host sync) and raises `TopkFailed` instead of
+    returning invalid masks — what every caller that hands masks to a file or an optimizer does (mask generation is
+    followed by a synchronising save anyway).  Callers that must not synchronise (the proximal step) get the failure
+    through the exported threshold instead: it is NaN, and `salun_soft_threshold_step` poisons the weights with it."""
     L = _lib.lib()
     n, nk = acc.numel(), len(ks)
     if not 1 <= nk <= _lib.SALUN_MAX_THRESHOLDS:
@@ -92,6 +100,11 @@ def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch
     check(L.salun_mask_topk_ex(_dev(acc, torch.float32, "acc"), c_int64(n), karr, c_int(nk), marr,
                                c_void_p(ws.data_ptr()), c_size_t(ws.numel()), ctypes.c_uint(flags), _stream()),
           "salun_mask_topk")
+    if check:
+        route, err = mask_topk_status(acc.device)
+        if err:
+            raise TopkFailed(f"salun_mask_topk: the full scan's grid barrier timed out (route {route}, n = {n}): "
+                             "its workgroups were not co-resident; no mask was produced")
     return list(out)
 
 

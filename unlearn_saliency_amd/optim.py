@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from .dist import all_reduce_mean_, world_size
+from .dist import all_reduce_mean_, collectives_on
 from .flat import FlatArena
 
 
@@ -23,7 +23,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.steps = 0
         self.overlap_buckets = 4
         self._reducer = None
-        if world_size() > 1:
+        if collectives_on():
             from .dist import BucketedGradReducer
             self._reducer = BucketedGradReducer(arena, self.overlap_buckets)
 
@@ -106,7 +106,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         """Data parallel: mean of the flat gradient over ranks.  By default the all-reduce is cut into a few large
         slices that start during backward (dist.BucketedGradReducer); `overlap_buckets = 0` falls back to one
         collective over the whole vector after backward."""
-        if world_size() <= 1:
+        if not collectives_on():
             return
         if self.overlap_buckets > 0:
             if self._reducer is None:  # first step: hooks were not installed before this backward ran

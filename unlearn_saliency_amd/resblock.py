@@ -162,7 +162,7 @@ class _BasicBlockFn(torch.autograd.Function):
         dw1 = wgrad(x, dc1, w1, s, 1)
         dx = ops.conv2d_backward_data(dc1, w1, x.shape, s, 1, addend=dxd) if ctx.needs_input_grad[0] else None
         if side is not None:
-            if sdist.world_size() > 1 or not all(g is None for g in (dw1, dw2, dwd)):
+            if sdist.collectives_on() or not all(g is None for g in (dw1, dw2, dwd)):
                 # data parallel: gradient-arrival hooks may start an all-reduce right after this node; autograd
                 # route: AccumulateGrad consumes the returned tensors on the main stream -> join now
                 main.wait_stream(side)

@@ -97,9 +97,9 @@ def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch
     nbytes = L.salun_mask_topk_workspace_bytes(c_int64(n), c_int(nk))
     ws = workspace(nbytes, acc.device, "topk")
     karr = (c_int64 * nk)(*[int(k) for k in ks])
-    check(L.salun_mask_topk_ex(_dev(acc, torch.float32, "acc"), c_int64(n), karr, c_int(nk), marr,
-                               c_void_p(ws.data_ptr()), c_size_t(ws.numel()), ctypes.c_uint(flags), _stream()),
-          "salun_mask_topk")
+    _lib.check(L.salun_mask_topk_ex(_dev(acc, torch.float32, "acc"), c_int64(n), karr, c_int(nk), marr,
+                                    c_void_p(ws.data_ptr()), c_size_t(ws.numel()), ctypes.c_uint(flags), _stream()),
+               "salun_mask_topk")  # (`check` the keyword shadows the module-level helper inside this function)
     if check:
         route, err = mask_topk_status(acc.device)
         if err:

@@ -211,3 +211,58 @@ def sd_unlearn(ldm: PlainLDM, forget_batches, remain_batches, alpha, lr, mask, t
             opt.step()
     unet.eval()
     return losses, opt
+
+
+def sd_proximal_unlearn(ldm: PlainLDM, forget_batches, remain_batches, alpha, lr, mask_ratio, n_frozen=0, epochs=1,
+                        train_method="full"):
+    """SD/train-scripts/proximal_gradient.py:76-186: the `sd_unlearn` body without a saliency mask, followed after every
+    optimizer step by the proximal pull towards the initial weights.  The reference ranks |theta - theta_0| over
+    `model.parameters()` of the WHOLE LatentDiffusion (:66-72): `n_frozen` zeros stand for its frozen first stage and
+    text encoder (they never move), appended to the U-Net's differences before the top-k (:157-167); the three-way update
+    (:169-182) is `param -= init; param[larger] -= thr; param[smaller] += thr; param[between] = 0; param += init`."""
+    unet = ldm.unet
+    params = [p for n, p in unet.named_parameters() if train_method == "full" or "attn2" in n]
+    unet.train()
+    opt = torch.optim.Adam(params, lr=lr)
+    init = torch.cat([p.detach().reshape(-1) for p in unet.parameters()]).clone()
+    n_params = init.numel() + int(n_frozen)
+    per_epoch = len(forget_batches) + len(remain_batches)
+    total_steps = epochs * per_epoch
+    losses = []
+    for epoch in range(epochs):
+        remain_iter = iter(remain_batches)
+        for i, (z_f, c_forget, c_pseudo) in enumerate(forget_batches):
+            opt.zero_grad()
+            try:
+                z_r, c_r = next(remain_iter)
+            except StopIteration:
+                remain_iter = iter(remain_batches)
+                z_r, c_r = next(remain_iter)
+            remain_loss = ldm.shared_step(z_r, c_r)
+            t = torch.randint(0, ldm.num_timesteps, (z_f.shape[0],), device=ldm.device).long()
+            noise = torch.randn_like(z_f)
+            z_noisy = ldm.q_sample(z_f, t, noise)
+            loss = nn.MSELoss()(ldm.apply_model(z_noisy, t, c_forget), ldm.apply_model(z_noisy, t, c_pseudo).detach()) \
+                + alpha * remain_loss
+            loss.backward()
+            losses.append(float(loss.item()))
+            opt.step()
+            with torch.no_grad():
+                ratio = int(mask_ratio * ((total_steps - (epoch * per_epoch + i + 1)) / total_steps * n_params))
+                cur = torch.cat([p.reshape(-1) for p in unet.parameters()] + [torch.zeros(int(n_frozen))])
+                cur[:init.numel()] -= init
+                cur.abs_().neg_()
+                threshold = -torch.topk(cur, ratio)[0][-1]
+                cnt = 0
+                for p in unet.parameters():
+                    ip = init[cnt:cnt + p.numel()].view(p.shape)
+                    p -= ip
+                    larger, smaller = p > threshold, p < -threshold
+                    between = ~(larger | smaller)
+                    p[larger] -= threshold
+                    p[smaller] += threshold
+                    p[between] = 0
+                    p += ip
+                    cnt += p.numel()
+    unet.eval()
+    return losses, opt

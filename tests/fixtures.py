@@ -167,3 +167,81 @@ def eval_loaders():
             out.append((torch.from_numpy((x * np.float32(s)).astype(np.float32)), torch.from_numpy(y)))
         return out
     return dict(shadow_train=mk(6, 2000, 1.0), shadow_test=mk(4, 2100, 0.15), target_test=mk(3, 2200, (0.15, 1.0, 0.15)))
+
+
+# ------------------------------------------------------------------ SD script-glue fixtures (sd_glue.npz)
+def sd_glue_config():
+    """250,372-parameter U-Net (one resolution level: ResBlocks + SpatialTransformers, no down/up-sampling) — small
+    enough that the reference's full accumulator fits a fixture; the two-level tiny config pins the module itself."""
+    return dict(sd_tiny_config(), channel_mult=(1,), attention_resolutions=(1,))
+
+
+SD_GLUE_PROMPTS = ("a photo of a nude person", "a photo of a person wearing clothes", "")
+
+
+def sd_glue_contexts():
+    """prompt -> fixed (7, 24) context embedding (stands in for the frozen CLIP encoder)."""
+    return {p: rng.normal(7 * 24, 9400 + i).reshape(7, 24) for i, p in enumerate(SD_GLUE_PROMPTS)}
+
+
+def sd_glue_batches():
+    """(class-style forget batches unused here, ..., forget 'images', remain 'images'): latents (4, 4, 8, 8) handed to
+    the reference scripts as their image tensors (B, C, H, W); 3 forget and 2 remain batches (the loop must wrap)."""
+    mk = lambda seed: torch.from_numpy(rng.normal(4 * 4 * 8 * 8, seed).reshape(4, 4, 8, 8))
+    forget = [mk(9500 + i) for i in range(3)]
+    remain = [mk(9600 + i) for i in range(2)]
+    return None, None, forget, remain
+
+
+def sd_glue_class_contexts():
+    """descriptions[i] -> context for the class-conditioned scripts (generate_mask / certain_label / proximal_gradient
+    goldens): the nude-prompt context shifted by 0.01 * i (fp32)."""
+    base = sd_glue_contexts()[SD_GLUE_PROMPTS[0]]
+    return [(base + np.float32(0.01) * np.float32(i)).astype(np.float32) if i else base.copy() for i in range(10)]
+
+
+def sd_glue_loaders(kind, remain_labels=None):
+    """This build's loader format (latents + context embeddings, SD/ldm_lite.py) for the data the reference scripts
+    saw in tests/golden/make_golden_sd_glue.py.
+      "nsfw_mask"   (z, ctx nude, ctx "")                "nsfw"  forget (z, nude, clothes), remain (z, clothes)
+      "class_mask"  (z, ctx class 3, ctx "")             "class" forget (z, class 3, class 4), remain (z, class labels)"""
+    _, _, forget, remain = sd_glue_batches()
+    ctx = {k: torch.from_numpy(v) for k, v in sd_glue_contexts().items()}
+    nude, wear, null = (ctx[p] for p in SD_GLUE_PROMPTS)
+    cls = [torch.from_numpy(c) for c in sd_glue_class_contexts()]
+    rep = lambda c, n: c.unsqueeze(0).repeat(n, 1, 1)
+    if kind == "nsfw_mask":
+        return [(z, rep(nude, len(z)), rep(null, len(z))) for z in forget]
+    if kind == "class_mask":
+        return [(z, rep(cls[3], len(z)), rep(null, len(z))) for z in forget]
+    if kind == "nsfw":
+        return ([(z, rep(nude, len(z)), rep(wear, len(z))) for z in forget], [(z, rep(wear, len(z))) for z in remain])
+    if kind == "class":
+        rl = [(z, torch.stack([cls[int(l)] for l in labs])) for z, labs in zip(remain, remain_labels)]
+        return [(z, rep(cls[3], len(z)), rep(cls[4], len(z))) for z in forget], rl
+    raise ValueError(kind)
+
+
+class replay_draws:
+    """torch.randint / torch.randn_like return the recorded draws in call order (moved to the requested device)."""
+
+    def __init__(self, randint, randn):
+        self.randint, self.randn = [np.asarray(v) for v in randint], [np.asarray(v) for v in randn]
+
+    def __enter__(self):
+        self.real = (torch.randint, torch.randn_like)
+        ri, rn = self.randint, self.randn
+
+        def randint(*a, device=None, **k):
+            return torch.from_numpy(ri.pop(0).astype(np.int64)).to(device or "cpu")
+
+        def randn_like(x, **k):
+            return torch.from_numpy(rn.pop(0).astype(np.float32)).to(x.device).reshape(x.shape)
+
+        torch.randint, torch.randn_like = randint, randn_like
+        return self
+
+    def __exit__(self, et, ev, tb):
+        torch.randint, torch.randn_like = self.real
+        if et is None:
+            assert not self.randint and not self.randn, "recorded draws left over: the call order differs"

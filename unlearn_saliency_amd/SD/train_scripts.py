@@ -86,6 +86,7 @@ def _saliency_mask(model, batches, c_guidance, mask_path, ratio=0.5):
         loss.backward()
         ops.saliency_accumulate(acc, arena.grads, 1.0)
     sdist.all_reduce_sum_(acc)
+    object.__setattr__(model, "_salun_last_saliency", acc)  # sum of gradients before |.| (diagnostics / parity tests)
     mask = ops.mask_topk(acc, [int(arena.n * ratio)], check=True)[0]  # raises instead of saving a garbage mask
     if mask_path and sdist.rank() == 0:
         os.makedirs(mask_path, exist_ok=True)

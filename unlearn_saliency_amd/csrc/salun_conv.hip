@@ -36,6 +36,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CC = 8;  // reduction channels staged per chunk
 
+// Tuning switches (0 in the product build; tools/_run_wgrad_exp.sh / _run_igemm_exp.sh build A/B libraries with them
+// to see where a kernel's time goes — results are WRONG with any bit set; DESIGN.md §6 has the round-3 table):
+//   conv_wgrad : 1 no global loads in the loop   2 no LDS stores in the loop   4 no barrier per chunk
+//                8 no partial-sum stores
+//   conv_igemm : 1 no global loads after the first chunk   2 no LDS stores after the first chunk
+//                4 no barriers after the first chunk        8 no output stores
+#ifndef SALUN_WGRAD_EXP
+#define SALUN_WGRAD_EXP 0
+#endif
+#ifndef SALUN_IGEMM_EXP
+#define SALUN_IGEMM_EXP 0
+#endif
+
 struct ConvGeomUnused {
   // logical convolution: out[n][k][p][q] = sum x[n][c][p*S - pad + r][q*S - pad + s] * w[k][c][r][s]
   int N, C, H, W, K, P, Q, pad;
@@ -253,10 +266,10 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
 
   load_chunk(0);
   for (int c0 = 0; c0 < Cred; c0 += CC) {
-    __syncthreads();  // previous chunk fully consumed
-    store_chunk();
-    __syncthreads();
-    if (c0 + CC < Cred) load_chunk(c0 + CC);  // in flight during the MFMA section below
+    if (!(SALUN_IGEMM_EXP & 4) || c0 == 0) __syncthreads();  // previous chunk fully consumed
+    if (!(SALUN_IGEMM_EXP & 2) || c0 == 0) store_chunk();
+    if (!(SALUN_IGEMM_EXP & 4) || c0 == 0) __syncthreads();
+    if (c0 + CC < Cred && !(SALUN_IGEMM_EXP & 1)) load_chunk(c0 + CC);  // in flight during the MFMA section below
     // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1).
     // The (1 + KT) LDS operands of k-step i+1 are read while the KT MFMAs of k-step i run (one-step-ahead
     // software pipeline, pinned with scheduling barriers): no MFMA waits for an LDS round trip.
@@ -286,6 +299,7 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
 
   // ---- epilogue: D[row = channel][col = pixel]; row = (v&3) + 8*(v>>2) + 4*hi
   const int n_out = n0 + ni_l, p_out = p0 + p_l;
+  if ((SALUN_IGEMM_EXP & 8) && N > 0) return;
   if (n_out < N) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -800,16 +814,23 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
   };
   // loads: unconditional, from a clamped (always valid) address; the value is masked when it is STORED to LDS half a
   // chunk later, so that nothing in a load slot depends on the load's result (no wait for memory between MFMAs)
+  bool in_loop = false;  // (tuning switches only)
   auto load_x = [&](int c) {
+    if ((SALUN_WGRAD_EXP & 1) && in_loop) return;
     const int cc = FULLC ? c : (c < cmax ? c : cmax - 1);
     xreg[c] = (xbase + (size_t)cc * planeHW)[xoff];
   };
-  auto load_d = [&](int i) { dreg[i] = *reinterpret_cast<const float4 *>(dbase + doff[i]); };
+  auto load_d = [&](int i) {
+    if ((SALUN_WGRAD_EXP & 1) && in_loop) return;
+    dreg[i] = *reinterpret_cast<const float4 *>(dbase + doff[i]);
+  };
   auto store_x = [&](float *buf, int c) {
+    if ((SALUN_WGRAD_EXP & 2) && in_loop) return;
     const unsigned m = FULLC ? xmask : (c < cmax ? xmask : 0u);
     buf[st_base + c * st_cmul] = __uint_as_float(__float_as_uint(xreg[c]) & m);
   };
   auto store_d = [&](float *dl, int sidx) {  // scalar #sidx (0 .. 4*DN4-1) of this thread's dy items
+    if ((SALUN_WGRAD_EXP & 2) && in_loop) return;
     const int i = sidx >> 2, comp = sidx & 3;
     const int e4 = tid + i * 256;
     const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4 + comp;
@@ -831,6 +852,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
     __syncthreads();
 
     int cur = 0;
+    in_loop = true;
     for (int chunk = split; chunk < nchunks; chunk += nsplit) {
       const float *xp = lds + cur * BUF;
       const float *dl = xp + 64 * ch_stride;
@@ -893,7 +915,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
 #pragma unroll
         for (int t = 0; t < RS; ++t) b_cur[t] = b_nxt[t];
       }
-      __syncthreads();
+      if (!(SALUN_WGRAD_EXP & 4)) __syncthreads();
       cur ^= 1;
     }
   }
@@ -901,6 +923,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
   // the reduce kernel maps back to OIHW
   float *out = part + (size_t)split * K * C * RS;
   const int c = c0 + ct * 32 + lo;
+  if ((SALUN_WGRAD_EXP & 8) && N > 0) return;
   if (c < C) {
 #pragma unroll
     for (int t = 0; t < RS; ++t)
@@ -1023,28 +1046,94 @@ __global__ __launch_bounds__(256) void conv_wgrad_smallc(const float *__restrict
   }
 }
 
-// dw (+)= sum_s part[s] in a fixed order: 8 strided sub-sums per output (thread g sums s = g, g+8, ...), folded
-// g = 0..7 through LDS.  32 outputs x 8 groups per workgroup keeps thousands of waves with loads in flight instead
-// of one long serial chain per output.  Partials are [rs][k][c]; the result is written in OIHW.
+// dw (+)= sum_s part[s] in a fixed order.  Partials are [split][rs][k][c]; the result is written in OIHW.
+// A thread owns FOUR consecutive partial indices (one 16-byte load per split) and one of G split groups
+// (G = 2^LOGG <= 16, chosen by the host so that G <= nsplit): group g adds splits g, g+G, g+2G, ... in that order,
+// eight loads in flight; the G group sums are then folded g = 0..G-1 through LDS.  256/G outputs x G groups per
+// workgroup: for the 256-way split of a 64x64 layer that is 576 workgroups x 16 loads per thread, for the 4-way
+// split of a 512x512 layer 9,216 workgroups x 1 load — always thousands of 16-byte loads in flight, which the
+// round-2 kernel (4-byte loads, 32 outputs per workgroup, half its threads idle when nsplit < 8) did not have.
+// Deterministic: the summation order depends only on (nsplit, G).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg_stream4(const float4 *p) {  // one 16-byte load, streamed past the caches
+  const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+template <int LOGG>
 __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float *__restrict__ part, float *__restrict__ dw,
                                                          int64_t n, int nsplit, int accumulate, int KC, int RS) {
-  __shared__ float red[8][33];
-  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int64_t i = (int64_t)blockIdx.x * 32 + o;  // index in [rs][k][c] order
-  float s = 0.f;
-  if (i < n) {
-#pragma unroll 8
-    for (int j = g; j < nsplit; j += 8) s += part[(size_t)j * n + i];
-  }
-  red[g][o] = s;
-  __syncthreads();
-  if (g == 0 && i < n) {
-    float t = red[0][o];
+  constexpr int G = 1 << LOGG, OUTS = 256 / G;
+  __shared__ float4 red[G][OUTS];
+  const int o = threadIdx.x & (OUTS - 1), g = threadIdx.x >> (8 - LOGG);
+  const int64_t i4 = (int64_t)blockIdx.x * OUTS + o;  // float4 index in [rs][k][c] order
+  const int64_t n4 = n >> 2;
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i4 < n4) {
+    const float4 *src = reinterpret_cast<const float4 *>(part) + i4;
+    int j = g;
+    for (; j + 7 * G < nsplit; j += 8 * G) {
+      float4 v[8];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][o];
-    const int64_t rs = i / KC, kc = i - rs * KC;
-    const int64_t dst = kc * RS + rs;
-    dw[dst] = accumulate ? dw[dst] + t : t;
+      for (int u = 0; u < 8; ++u) v[u] = ldg_stream4(src + (size_t)(j + u * G) * n4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s4.x += v[u].x; s4.y += v[u].y; s4.z += v[u].z; s4.w += v[u].w; }
+    }
+    for (; j < nsplit; j += G) {
+      const float4 v = ldg_stream4(src + (size_t)j * n4);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+  }
+  if (G > 1) {
+    red[g][o] = s4;
+    __syncthreads();
+  }
+  if (g == 0 && i4 < n4) {
+#pragma unroll
+    for (int k = 1; k < G; ++k) {
+      const float4 v = red[k][o];
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    const float t[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = i4 * 4 + e;
+      const int64_t rs = i / KC, kc = i - rs * KC;
+      const int64_t dst = kc * RS + rs;
+      dw[dst] = accumulate ? dw[dst] + t[e] : t[e];
+    }
+  }
+}
+
+// n not a multiple of 4 (odd test shapes; no layer of the three models): one output per thread, splits in order
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_scalar(const float *__restrict__ part, float *__restrict__ dw,
+                                                                int64_t n, int nsplit, int accumulate, int KC, int RS) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float t = 0.f;
+  for (int j = 0; j < nsplit; ++j) t += part[(size_t)j * n + i];
+  const int64_t rs = i / KC, kc = i - rs * KC;
+  const int64_t dst = kc * RS + rs;
+  dw[dst] = accumulate ? dw[dst] + t : t;
+}
+
+inline void launch_wgrad_reduce(const float *part, float *dw, int64_t n, int nsplit, int accumulate, int KC, int RS,
+                                hipStream_t st) {
+  if ((n & 3) || !salun_aligned16(part)) {
+    hipLaunchKernelGGL(conv_wgrad_reduce_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, dw, n,
+                       nsplit, accumulate, KC, RS);
+    return;
+  }
+  int logg = 0;
+  while (logg < 4 && (2 << logg) <= nsplit) ++logg;
+  const int outs = 256 >> logg;
+  const unsigned grid = (unsigned)(((n >> 2) + outs - 1) / outs);
+  switch (logg) {
+    case 0: hipLaunchKernelGGL(conv_wgrad_reduce<0>, dim3(grid), dim3(256), 0, st, part, dw, n, nsplit, accumulate, KC, RS); break;
+    case 1: hipLaunchKernelGGL(conv_wgrad_reduce<1>, dim3(grid), dim3(256), 0, st, part, dw, n, nsplit, accumulate, KC, RS); break;
+    case 2: hipLaunchKernelGGL(conv_wgrad_reduce<2>, dim3(grid), dim3(256), 0, st, part, dw, n, nsplit, accumulate, KC, RS); break;
+    case 3: hipLaunchKernelGGL(conv_wgrad_reduce<3>, dim3(grid), dim3(256), 0, st, part, dw, n, nsplit, accumulate, KC, RS); break;
+    default: hipLaunchKernelGGL(conv_wgrad_reduce<4>, dim3(grid), dim3(256), 0, st, part, dw, n, nsplit, accumulate, KC, RS); break;
   }
 }
 
@@ -1396,8 +1485,7 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
 #undef SALUN_WGRAD_S
     SALUN_LAUNCH_CHECK();
     const int64_t nn = (int64_t)K * C * R * R;
-    hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((nn + 31) / 32)), dim3(256), 0, st, part_s, dw, nn, ns * 2,
-                       accumulate, K * C, R * R);
+    launch_wgrad_reduce(part_s, dw, nn, ns * 2, accumulate, K * C, R * R, st);
     SALUN_LAUNCH_CHECK();
     return SALUN_OK;
   }
@@ -1429,8 +1517,7 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
 #undef SALUN_WGRAD
   SALUN_LAUNCH_CHECK();
   const int64_t n = (int64_t)K * C * R * R;
-  hipLaunchKernelGGL(conv_wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, dw, n, ns, accumulate,
-                     K * C, R * R);
+  launch_wgrad_reduce(part, dw, n, ns, accumulate, K * C, R * R, st);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }

@@ -14,6 +14,14 @@ import ddpm_ref_cpu as R
 from fixtures import ddpm_batch, ddpm_small_config, fill_params, flat_params
 
 pytestmark = pytest.mark.gpu
+
+# Tolerances against the reference-run goldens = 3 x the error measured on the MI355X (printed by every test; round 3:
+# forward 4.3e-6, accumulator sample 9.6e-6, Fisher 1.1e-5 / 2.0e-4 relative, Adam moments 1.5e-5 of scale)
+FWD_TOL = 2e-5
+ACC_TOL = 3e-5
+FIM_TOL = 4e-5
+FIM_REL_TOL = 6e-4
+MOMENT_TOL = 5e-5
 STRIDE = 997
 
 
@@ -86,7 +94,9 @@ def test_unet_forward_on_gpu_matches_reference(golden_dir):
     with torch.no_grad():
         out = model(t_(2 * xb - 1), tb, t_(cb), mode="test", cond_scale=2.0).cpu().numpy()
     ref = core["fwd_test_s2"]
-    assert np.allclose(out, ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())
+    err = float(np.abs(out - ref).max() / np.abs(ref).max())
+    print(f"DDPM U-Net forward on the device vs the reference's output: max |err| = {err:.2e} of the output's scale")
+    assert err <= FWD_TOL, err
 
 
 def test_generate_mask_matches_reference(golden_dir, workdir):
@@ -104,14 +114,26 @@ def test_generate_mask_matches_reference(golden_dir, workdir):
     assert np.array_equal(flat, masks[0.5].cpu().numpy())
     ref_mask = np.unpackbits(g["mask_packed"])[:n]
     assert int(flat.sum()) == int(g["popcount"])
-    assert (flat != ref_mask).mean() < 2e-3
+    # bit-exact OUTSIDE the threshold band: every position where this mask differs from the reference's is one whose
+    # reference saliency lies within 1e-3 (relative) of the reference's threshold tau (the golden lists those 6,083
+    # positions of 12.3 M) — i.e. the only freedom is the accumulator's fp32 round-off right at the cut
+    flips = np.flatnonzero(flat != ref_mask)
+    outside = np.setdiff1d(flips, g["near_idx"])
+    print(f"generate_mask: {flips.size} of {n} positions differ from the reference's mask, {outside.size} of them outside "
+          f"the +-1e-3 band around tau ({g['near_idx'].size} positions)")
+    assert outside.size == 0, outside[:10]
+    assert flips.size <= g["near_idx"].size
     # the accumulator itself
     model = runner._load_model()
     with R.replay(randn=g["randn"], randint=g["randint"]):
         acc = runner.accumulate_saliency(model, _batches(400, label=0)).cpu().numpy()
     ref_norm = float(g["acc_norm"])
     assert abs(np.linalg.norm(acc.astype(np.float64)) - ref_norm) <= 1e-5 * ref_norm
-    assert np.allclose(acc[::STRIDE], g["acc_sample"], rtol=1e-4, atol=2e-5 * np.abs(g["acc_sample"]).max())
+    err = float(np.abs(acc[::STRIDE] - g["acc_sample"]).max() / np.abs(g["acc_sample"]).max())
+    near = float(np.abs(np.abs(acc[g["near_idx"]]) - g["near_abs"]).max() / float(g["tau"]))
+    print(f"generate_mask: accumulator sample max |err| = {err:.2e} of scale; at the threshold band {near:.2e} of tau")
+    assert err <= ACC_TOL, err
+    assert near <= 1e-3, near  # elements of the band stay in a band of twice the width: nothing far away can cross
 
 
 @pytest.mark.parametrize("method", ["rl", "ga"])
@@ -155,8 +177,7 @@ def test_saliency_unlearn_matches_reference(golden_dir, workdir, method):
     d1 = np.abs(m1[::STRIDE] - g["exp_avg_sample"]) / s1
     d2 = np.abs(v[::STRIDE] - g["exp_avg_sq_sample"]) / s2
     print(f"{method}: exp_avg max dev {d1.max():.2e} of scale, exp_avg_sq max dev {d2.max():.2e} of scale")
-    assert np.allclose(m1[::STRIDE], g["exp_avg_sample"], rtol=1e-3, atol=1e-5 * s1), d1.max()
-    assert np.allclose(v[::STRIDE], g["exp_avg_sq_sample"], rtol=2e-3, atol=1e-5 * s2), d2.max()
+    assert d1.max() <= MOMENT_TOL and d2.max() <= MOMENT_TOL, (d1.max(), d2.max())
     assert abs(np.linalg.norm(m1.astype(np.float64)) - float(g["exp_avg_norm"])) <= 1e-5 * float(g["exp_avg_norm"])
     assert abs(v.astype(np.float64).sum() - float(g["exp_avg_sq_sum"])) <= 2e-5 * float(g["exp_avg_sq_sum"])
     assert not m1[mask == 0].any() and not v[mask == 0].any()
@@ -164,8 +185,17 @@ def test_saliency_unlearn_matches_reference(golden_dir, workdir, method):
     #     near-zero-gradient elements agree to a small fraction of lr; per-tensor sums to 1e-4
     lr = cfg.optim.lr
     got, ref = after[::STRIDE], g["param_sample"]
-    close = np.abs(got - ref) <= 0.02 * lr + 1e-6 * np.abs(ref)
-    assert close.mean() > 0.99, close.mean()
+    # the MOVEMENT p - p0 against the reference's, where the reference moved at all: Adam's normalised step is
+    # m_hat / (sqrt(v_hat) + eps), so a weight whose gradient is not tiny against eps = 1e-8 moves by the same amount
+    # on both sides up to the moments' round-off; the few whose |g| is within round-off of 0 may flip a whole lr and
+    # are counted (bound: 5e-3 of the sample)
+    p0 = before[::STRIDE]
+    dgot, dref = got - p0, ref - p0
+    moved = np.abs(dref) > 0
+    bad = np.abs(dgot - dref) > 1e-4 * np.abs(dref) + 1e-3 * lr
+    print(f"{method}: {int(moved.sum())} sampled weights moved in the reference run; movement differs by more than "
+          f"1e-4 relative + 1e-3 lr on {int(bad.sum())} of {bad.size}")
+    assert bad.mean() <= 5e-3, bad.mean()
     assert np.abs(got - ref).max() <= 2 * 2 * lr   # two steps, at most +-lr each on both sides
     sums = np.array([float(p.detach().double().sum()) for p in model.parameters()])
     assert np.allclose(sums, g["tensor_sums"], rtol=1e-4, atol=3e-3)
@@ -211,7 +241,10 @@ def test_save_fim_matches_reference(golden_dir, workdir):
     assert list(fd.keys()) == list(g["keys"])
     F = np.concatenate([v.reshape(-1).cpu().numpy() for v in fd.values()])
     assert abs(F.astype(np.float64).sum() - float(g["F_sum"])) <= 1e-4 * float(g["F_sum"])
-    assert np.allclose(F[::STRIDE], g["F_sample"], rtol=1e-3, atol=2e-5 * np.abs(g["F_sample"]).max())
+    err = float(np.abs(F[::STRIDE] - g["F_sample"]).max() / np.abs(g["F_sample"]).max())
+    rel = np.abs(F[::STRIDE] - g["F_sample"]) / np.maximum(np.abs(g["F_sample"]), 1e-3 * np.abs(g["F_sample"]).max())
+    print(f"save_fim: max |err| = {err:.2e} of scale, max relative (elements above 1e-3 of scale) {rel.max():.2e}")
+    assert err <= FIM_TOL and rel.max() <= FIM_REL_TOL, (err, rel.max())
     assert os.path.exists(os.path.join(workdir, "fisher_dict.pkl"))
 
 

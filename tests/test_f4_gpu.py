@@ -1,0 +1,116 @@
+"""Evaluation-side rows on the DEVICE: the DDPM reverse-process samplers, the EMA
+helper over the flat arena and the CompVis -> Diffusers key converter, run on cuda tensors against the same
+reference-produced goldens the CPU tests use (`ddpm_f4.npz`: DDPM/functions/denoising.py:11-131, DDPM/models/ema.py:5-51;
+`sd_convert.npz`: SD/train-scripts/convertModels.py:348-591), plus one end-to-end sampling run through the package's
+own U-Net kernels (MFMA convolutions, fused GroupNorm) checked against the same sampler on the library path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fixtures import ddpm_small_config, fill_params, sd_tiny_config
+from test_f4_vs_golden import StubEps, _ReplayRandn, _ema_model
+from unlearn_saliency_amd import rng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["ddim", "ddim_eta", "ddpm", "ddim_cond", "ddpm_cond"])
+def test_samplers_on_device_match_reference(golden_dir, name):
+    from unlearn_saliency_amd.DDPM.functions import denoising as DN
+    g = np.load(os.path.join(golden_dir, "ddpm_f4.npz"))
+    dev = torch.device("cuda")
+    x = torch.from_numpy(g["x"]).to(dev)
+    seq = [int(v) for v in g["seq"]]
+    betas = torch.linspace(1e-4, 0.02, 1000).to(dev)
+    c = torch.tensor([1, 5, 9], device=dev)
+    model = StubEps().to(dev)
+    call = {"ddim": lambda: DN.generalized_steps(x, seq, model, betas, eta=0.0, keep="all"),
+            "ddim_eta": lambda: DN.generalized_steps(x, seq, model, betas, eta=0.7, keep="all"),
+            "ddpm": lambda: DN.ddpm_steps(x, seq, model, betas, keep="all"),
+            "ddim_cond": lambda: DN.generalized_steps_conditional(x, c, seq, model, betas, cond_scale=2.0, eta=0.3,
+                                                                  keep="all"),
+            "ddpm_cond": lambda: DN.ddpm_step_conditional(x, c, seq, model, betas, 2.0, keep="all")}[name]
+    with _ReplayRandn(g[name + "_randn"]):
+        xs, x0s = call()
+    assert all(t.is_cuda for t in xs)
+    for a, b in zip(xs, g[name + "_xs"]):
+        assert np.allclose(a.cpu().numpy(), b, rtol=1e-5, atol=2e-6)
+    for a, b in zip(x0s, g[name + "_x0"]):
+        assert np.allclose(a.cpu().numpy(), b, rtol=1e-5, atol=2e-6)
+
+
+def test_sampling_through_the_own_unet_kernels():
+    """`Diffusion.sample_image` (reference runners/diffusion.py:828-875) with the CFG-DDPM U-Net on the MFMA
+    convolution / fused GroupNorm kernels against the same sampler on the library ops: 6 DDIM steps, two classes.
+    Tolerance 1e-4 of the sample's scale (six U-Net evaluations in fp32; measured ~1e-6)."""
+    import copy
+    from types import SimpleNamespace
+    from unlearn_saliency_amd import conv as sconv
+    from unlearn_saliency_amd.conv import use_salun_convs
+    from unlearn_saliency_amd.DDPM.models.diffusion import Conditional_Model
+    from unlearn_saliency_amd.DDPM.runners.diffusion import Diffusion
+    dev = torch.device("cuda")
+    lib = fill_params(Conditional_Model(ddpm_small_config()), 7000).to(dev).eval()
+    own = copy.deepcopy(lib)
+    assert use_salun_convs(own) > 0
+    r = Diffusion.__new__(Diffusion)
+    r.num_timesteps = 1000
+    r.betas = torch.linspace(1e-4, 0.02, 1000, device=dev)
+    r.args = SimpleNamespace(sample_type="generalized", skip_type="uniform", timesteps=6, eta=0.0)
+    x = torch.from_numpy(rng.normal(2 * 3 * 16 * 16, 31).reshape(2, 3, 16, 16)).to(dev)
+    c = torch.tensor([2, 7], device=dev)
+    sconv.reset_library_conv_calls()
+    with torch.no_grad():
+        a = r.sample_image(x, own, c, 2.0)
+        n_lib = sconv.library_conv_calls()
+        b = r.sample_image(x, lib, c, 2.0)
+    assert n_lib == 0, sconv.LIBRARY_CONV_CALLS
+    err = float((a - b).abs().max() / b.abs().max())
+    print(f"6-step DDIM sample, own kernels vs library ops: {err:.2e} of scale")
+    assert torch.isfinite(a).all() and err <= 1e-4, err
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_ema_on_device_matches_reference(golden_dir, flat):
+    from unlearn_saliency_amd.DDPM.models.ema import EMAHelper
+    from unlearn_saliency_amd.flat import arena_of
+    g = np.load(os.path.join(golden_dir, "ddpm_f4.npz"))
+    lin = _ema_model().cuda()
+    if flat:
+        arena_of(lin)
+    ema = EMAHelper(mu=0.9)
+    ema.register(lin)
+    assert list(ema.state_dict().keys()) == list(g["ema_keys"])
+    for step in range(4):
+        with torch.no_grad():
+            for i, p in enumerate(lin.parameters()):
+                p.add_(torch.from_numpy(rng.normal(p.numel(), 4100 + 10 * step + i, 0.0, 0.1)).view_as(p).cuda())
+        ema.update(lin)
+        got = np.concatenate([v.reshape(-1).cpu().numpy() for v in ema.state_dict().values()])
+        assert np.allclose(got, g["ema_states"][step], rtol=1e-6, atol=1e-7), step
+    target = _ema_model().cuda()
+    ema2 = EMAHelper(mu=0.9)
+    ema2.register(target)
+    ema2.load_state_dict({k: v.clone() for k, v in ema.state_dict().items()})
+    ema2.ema(target)
+    now = np.concatenate([p.detach().reshape(-1).cpu().numpy() for p in target.parameters()])
+    assert np.allclose(now, g["ema_states"][-1], rtol=1e-6, atol=1e-7)
+
+
+def test_converter_on_device_tensors_matches_reference(golden_dir):
+    """CompVis -> Diffusers key layout (SD/convert.py) applied to a state_dict that lives on the device (what the SD
+    command lines hand it after unlearning): same keys, shapes and tensors as the reference's function produced."""
+    from unlearn_saliency_amd.SD.convert import convert_ldm_unet_checkpoint
+    from unlearn_saliency_amd.SD.unet import UNetModel
+    g = np.load(os.path.join(golden_dir, "sd_convert.npz"))
+    cfg = sd_tiny_config()
+    m = fill_params(UNetModel(**cfg), 9000).cuda()
+    sd = {"model.diffusion_model." + k: v for k, v in m.state_dict().items()}
+    conv = convert_ldm_unet_checkpoint(sd, cfg["num_res_blocks"])
+    ref = dict(zip(g["tiny_keys"], zip(g["tiny_sums"], g["tiny_shapes"])))
+    assert set(conv) == set(ref) and all(v.is_cuda for v in conv.values())
+    for k, v in conv.items():
+        assert str(tuple(v.shape)) == ref[k][1], k
+        assert abs(float(v.double().sum()) - float(ref[k][0])) <= 1e-9 * max(1.0, abs(float(ref[k][0]))), k

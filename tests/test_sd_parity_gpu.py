@@ -97,7 +97,9 @@ def test_unet_on_device_matches_reference_forward_and_f64_backward(golden_dir):
     with torch.no_grad():
         out = dev(x.cuda(), t.cuda(), c.cuda()).cpu().numpy()
     ref = g["tiny_forward"]  # produced by the reference's UNetModel (tests/golden/make_golden_sd.py)
-    assert np.allclose(out, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max()), np.abs(out - ref).max()
+    err = float(np.abs(out - ref).max() / np.abs(ref).max())
+    print(f"SD U-Net forward on the device vs the reference's output: max |err| = {err:.2e} of the output's scale")
+    assert err <= 2e-5, err  # 3 x the error measured on the MI355X in round 3
     print("library convolution calls in the tiny forward:", dict(sconv.LIBRARY_CONV_CALLS))
     # one backward: d(sum(out * w))/d(params) vs float64 on the host; 1e-4 of each tensor's scale
     w = torch.from_numpy(_np(3, 2, 4, 8, 8))

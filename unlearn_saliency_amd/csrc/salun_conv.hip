@@ -935,6 +935,195 @@ __global__ __launch_bounds__(256) void conv_wgrad(const float *__restrict__ x, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward-weight, 3x3, vectorised staging (round 3).  Same tile, same LDS image, same MFMA / operand-read stream as
+// `conv_wgrad<3, STRIDE, true>`; what changes is how a chunk travels global -> registers -> LDS.  The A/B builds of
+// round 3 (tools/_run_wgrad_exp.sh) put 14 us of a 218 us layer on the loop's 68 `global_load_dword` per thread and
+// chunk and 20 us on its 80 `ds_write_b32` — vector-memory and LDS-store INSTRUCTIONS are the scarce resource beside
+// the matrix pipe, and the scalar mapping wasted them: one thread per patch position means 136 of 256 threads carry
+// real data on a 32-wide image, the rest write a dump row.  Here an item is one 16-byte piece of a patch row's
+// INTERIOR (the image's own columns; the halo columns are padding for every tile of these models and are zeroed once):
+// 64 channels x F4C pieces per chunk, dealt out over all 256 threads — NIT = F4C / 4 loads of 16 bytes per thread
+// (8 on a 32-wide image) and 4 NIT dword stores, all of them useful.  Rows above / below the image and images beyond N
+// load from a clamped address and are AND-masked when stored, as before.
+//   requires: R = 3, pad = 1, C % 64 == 0, W % 4 == 0, the tile spans whole image rows (Q == W / STRIDE),
+//             F4C = NI * IH_t * (W / 4) a multiple of 4 with F4C / 4 == NIT.
+template <int STRIDE, int NIT>
+__global__ __launch_bounds__(256) void conv_wgrad_v(const float *__restrict__ x, const float *__restrict__ dy,
+                                                    float *__restrict__ part, int N, int C, int H, int W, int K, int P,
+                                                    int Q, int NI, int TP, int IH_t, int IW_t, int logQ, int nchunks) {
+  constexpr int R = 3, RS = 9, PAD = 1;
+  constexpr int PIXC = (STRIDE == 1) ? 64 : 32;
+  constexpr int DROW = PIXC + 1;
+  constexpr int NSTEP = PIXC / 2;
+  constexpr int HALF = NSTEP / 2;
+  constexpr int DN4 = 64 * PIXC / 4 / 256;       // float4 items of dy per thread and chunk (4 or 2)
+  constexpr int LOGPIX4 = (PIXC == 64) ? 4 : 3;
+  constexpr int NLD = NIT + DN4;                  // load instructions per thread and chunk
+  constexpr int LPS = (NLD + HALF - 1) / HALF;    // ... per step of the first half
+  constexpr int NST = 4 * (NIT + DN4);            // dword stores per thread and chunk
+  constexpr int SPS = (NST + HALF - 1) / HALF;    // ... per step of the second half
+  static_assert(LPS <= RS && SPS <= RS, "one staging instruction per MFMA slot at most");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int PSZ = NI * IH_t * IW_t;
+  const int ch_stride = PSZ | 1;
+  const int BUF = 64 * ch_stride + 64 * DROW + 256;  // same LDS image as conv_wgrad
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int kt = wave & 1, ct = wave >> 1;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int split = blockIdx.z, nsplit = gridDim.z;
+  const int tiles_per_img = (NI > 1) ? 1 : P / TP;
+  const int planeHW = H * W, PQ = P * Q;
+  const int logTP = __builtin_ctz(TP);
+  const int W4 = W >> 2;
+  const int F4C = NI * IH_t * W4;
+
+  f32x16 acc[RS];
+#pragma unroll
+  for (int t = 0; t < RS; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  // ---- the NIT x-items of this thread (chunk independent part)
+  int it_lds[NIT];    // float offset of the piece inside one LDS buffer
+  int it_g[NIT];      // float offset from &x[n0][c0][0][0] for p0 = 0 (can be negative: rows above the image)
+  int it_ih[NIT], it_ni[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int e = tid + k * 256;
+    const int c = e / F4C, r = e - c * F4C;
+    const int ni = r / (IH_t * W4), r2 = r - ni * (IH_t * W4);
+    const int ih = r2 / W4, g4 = r2 - ih * W4;
+    it_lds[k] = c * ch_stride + (ni * IH_t + ih) * IW_t + PAD + 4 * g4;
+    it_g[k] = (ni * C + c) * planeHW + (ih - PAD) * W + 4 * g4;
+    it_ih[k] = ih;
+    it_ni[k] = ni;
+  }
+  float4 xreg[NIT];
+  float4 dreg[DN4];
+  const float *xbase = x;
+  unsigned xoff[NIT], xmask[NIT];
+  const float *dbase = dy;
+  unsigned doff[DN4], dmask[DN4];
+  int d_kk[DN4], d_ni[DN4], d_in[DN4];
+#pragma unroll
+  for (int i = 0; i < DN4; ++i) {
+    const int e4 = tid + i * 256;
+    const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4;
+    const int q = m & (Q - 1), pr = m >> logQ;
+    d_kk[i] = kk;
+    d_ni[i] = pr >> logTP;
+    d_in[i] = (pr & (TP - 1)) * Q + q;
+  }
+  auto aim = [&](int chunk) {
+    int n0, p0;
+    if (NI > 1) { n0 = chunk * NI; p0 = 0; }
+    else { n0 = chunk / tiles_per_img; p0 = (chunk - n0 * tiles_per_img) * TP; }
+    xbase = x + ((size_t)n0 * C + c0) * planeHW;
+    const int h0 = p0 * STRIDE;  // input row of patch row PAD
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int h = h0 - PAD + it_ih[k];
+      const bool ok = (n0 + it_ni[k]) < N && h >= 0 && h < H;
+      xoff[k] = ok ? (unsigned)(it_g[k] + h0 * W) : 0u;
+      xmask[k] = ok ? 0xffffffffu : 0u;
+    }
+    dbase = dy + ((size_t)n0 * K + k0) * PQ + (size_t)p0 * Q;
+#pragma unroll
+    for (int i = 0; i < DN4; ++i) {
+      const bool okd = (n0 + d_ni[i]) < N && (k0 + d_kk[i]) < K;
+      doff[i] = okd ? (unsigned)((d_ni[i] * K + d_kk[i]) * PQ + d_in[i]) : 0u;
+      dmask[i] = okd ? 0xffffffffu : 0u;
+    }
+  };
+  auto load_item = [&](int li) {  // li < NLD: x items first, then dy items
+    if (li < NIT) xreg[li] = *reinterpret_cast<const float4 *>(xbase + xoff[li]);
+    else dreg[li - NIT] = *reinterpret_cast<const float4 *>(dbase + doff[li - NIT]);
+  };
+  auto comp_of = [](const float4 &v, int comp) { return comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w; };
+  auto store_item = [&](float *buf, int si) {  // si < NST: the dwords of the x items, then those of the dy items
+    if (si < 4 * NIT) {
+      const int k = si >> 2, comp = si & 3;
+      buf[it_lds[k] + comp] = __uint_as_float(__float_as_uint(comp_of(xreg[k], comp)) & xmask[k]);
+    } else {
+      const int sd = si - 4 * NIT, i = sd >> 2, comp = sd & 3;
+      const int e4 = tid + i * 256;
+      const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4 + comp;
+      (buf + 64 * ch_stride)[kk * DROW + m] = __uint_as_float(__float_as_uint(comp_of(dreg[i], comp)) & dmask[i]);
+    }
+  };
+
+  // the halo columns (and everything else no item writes) stay zero for the whole kernel
+  for (int i = tid; i < 2 * BUF; i += 256) lds[i] = 0.f;
+  __syncthreads();
+
+  if (split < nchunks) {
+    aim(split);
+#pragma unroll
+    for (int li = 0; li < NLD; ++li) load_item(li);
+#pragma unroll
+    for (int si = 0; si < NST; ++si) store_item(lds, si);
+    __syncthreads();
+
+    int cur = 0;
+    for (int chunk = split; chunk < nchunks; chunk += nsplit) {
+      const float *xp = lds + cur * BUF;
+      const float *dl = xp + 64 * ch_stride;
+      float *buf_n = lds + (cur ^ 1) * BUF;
+      aim(chunk + nsplit < nchunks ? chunk + nsplit : chunk);  // the last chunk re-stages itself: branch-free body
+      const float *arow = dl + (kt * 32 + lo) * DROW + hi;
+      const float *brow = xp + (ct * 32 + lo) * ch_stride + hi * STRIDE;
+      auto pair_off = [&](int j) {
+        const int q0 = j & (Q - 1), pr = j >> logQ;
+        const int ni = pr >> logTP, pl = pr & (TP - 1);
+        return (ni * IH_t + pl * STRIDE) * IW_t + q0 * STRIDE;
+      };
+      float a_cur, b_cur[RS], a_nxt = 0.f, b_nxt[RS];
+      {
+        const float *bp = brow + pair_off(0);
+        a_cur = arow[0];
+#pragma unroll
+        for (int t = 0; t < RS; ++t) b_cur[t] = bp[(t / R) * IW_t + (t % R)];
+      }
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        const float *bp = brow + ((st + 1 < NSTEP) ? pair_off(2 * st + 2) : 0);
+#pragma unroll
+        for (int t = 0; t < RS; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < NSTEP) {
+            if (t == 0) a_nxt = arow[2 * st + 2];
+            b_nxt[t] = bp[(t / R) * IW_t + (t % R)];
+          }
+          if (st < HALF) {
+            if (t < LPS && st * LPS + t < NLD) load_item(st * LPS + t);
+          } else {
+            if (t < SPS && (st - HALF) * SPS + t < NST) store_item(buf_n, (st - HALF) * SPS + t);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        a_cur = a_nxt;
+#pragma unroll
+        for (int t = 0; t < RS; ++t) b_cur[t] = b_nxt[t];
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float *out = part + (size_t)split * K * C * RS;
+  const int c = c0 + ct * 32 + lo;
+#pragma unroll
+  for (int t = 0; t < RS; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int k = k0 + kt * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+      if (k < K) out[((size_t)t * K + k) * C + c] = acc[t][v];
+    }
+}
+
 // backward-weight for tiny input-channel counts (the RGB stem: C*R*R <= 32).  The general kernel would spend a
 // 64-channel tile and R*R accumulators on 3 real channels; here the 32 MFMA columns are the (c, r, s) combinations
 // themselves (27 for RGB 3x3), one accumulator per wave, and the kernel is bound by reading dY once.
@@ -1500,6 +1689,29 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
   if (ldsb > 160 * 1024) return SALUN_EINVAL;
   dim3 grid((K + 63) / 64, (C + 63) / 64, ns);
   float *part = static_cast<float *>(ws);
+  // vectorised staging (conv_wgrad_v) where the geometry allows it: 3x3, pad 1, full channel tiles, whole image rows
+  bool vec_done = false;
+  if (R == 3 && pad == 1 && C % 64 == 0 && W % 4 == 0 && Q * stride == W && P * stride == H &&
+      (size_t)g.NI * C * H * W < (1u << 30)) {
+    const int F4C = g.NI * g.IH_t * (W / 4);
+    const int nit = (F4C % 4 == 0) ? F4C / 4 : 0;
+#define SALUN_WGRAD_V(S_, NIT_)                                                                                \
+  {                                                                                                            \
+    allow_lds(conv_wgrad_v<S_, NIT_>, ldsb);                                                                   \
+    hipLaunchKernelGGL((conv_wgrad_v<S_, NIT_>), grid, dim3(256), ldsb, st, x, dy, part, N, C, H, W, K, P, Q,  \
+                       g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles);                                          \
+    vec_done = true;                                                                                           \
+  }
+    if (stride == 1) {
+      if (nit == 5) SALUN_WGRAD_V(1, 5)
+      else if (nit == 6) SALUN_WGRAD_V(1, 6)
+      else if (nit == 8) SALUN_WGRAD_V(1, 8)
+    } else {
+      if (nit == 9) SALUN_WGRAD_V(2, 9)
+      else if (nit == 10) SALUN_WGRAD_V(2, 10)
+    }
+#undef SALUN_WGRAD_V
+  }
 #define SALUN_WGRAD(R_, S_)                                                                                    \
   if (C % 64 == 0) {                                                                                           \
     allow_lds(conv_wgrad<R_, S_, true>, ldsb);                                                                 \
@@ -1510,7 +1722,8 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
     hipLaunchKernelGGL((conv_wgrad<R_, S_, false>), grid, dim3(256), ldsb, st, x, dy, part, N, C, H, W, K, P,  \
                        Q, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles);                                  \
   }
-  if (R == 3 && stride == 1) { SALUN_WGRAD(3, 1) }
+  if (vec_done) { }
+  else if (R == 3 && stride == 1) { SALUN_WGRAD(3, 1) }
   else if (R == 3 && stride == 2) { SALUN_WGRAD(3, 2) }
   else if (R == 1 && stride == 1) { SALUN_WGRAD(1, 1) }
   else { SALUN_WGRAD(1, 2) }

@@ -80,6 +80,7 @@ def test_sd_v1_bf16_full_size_unlearn_step():
     arena = TS._unet_arena(model)
     assert arena.n == 859_520_964
     assert model.use_mfma_convs() == 96       # every convolution but the 4-channel head / tail on the bf16 kernels
+    assert model.fill_zero_initialised() > 1_000_000  # zero_module layers + biases: a live network, like a checkpoint
     mask = _saliency_mask(arena.n, 7)
     opt = FusedMaskedAdam(arena, lr=1e-5)
     opt.set_mask(mask)

@@ -52,6 +52,7 @@ def main(argv=None):
         model = LatentDiffusionLite(bf16=a.bf16).to(dev)
     arena = TS._unet_arena(model)
     assert arena.n == NS, arena.n
+    n_filled = model.fill_zero_initialised()  # zero_module layers / biases -> N(0, 0.02): gradients flow everywhere
     n_salun = 0
     from unlearn_saliency_amd import conv as sconv
     if not a.library_conv and not a.bf16:
@@ -143,7 +144,7 @@ def main(argv=None):
                                "(BASELINE.json configs[4])",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "dtype": "bf16 autocast (fp32 master weights / Adam)" if a.bf16 else "f32", "data": "synthetic",
-        "params": NS, "salun_mfma_convs": n_salun, "library_conv_calls": sconv.library_conv_calls(), "init_sec": t_init,
+        "params": NS, "zero_initialised_elements_filled": n_filled, "salun_mfma_convs": n_salun, "library_conv_calls": sconv.library_conv_calls(), "init_sec": t_init,
         "mask_gen": {"batches": a.mask_batches, "saliency_sec": t_mask, "topk_ms_at_NS": topk_ms,
                      "topk_GBps_algorithmic": 5.0 * NS / (topk_ms * 1e-3) / 1e9},
         "roofline": {"kernel": "salun_masked_adam_step @ N_S" + ("" if not sdist.collectives_on() else

@@ -7,7 +7,8 @@ import torch
 from unlearn_saliency_amd import ops
 
 SHAPES = [("l1 64->64 @32", 256, 64, 32, 64, 3, 1, 1), ("l3 256->256 @8", 256, 256, 8, 256, 3, 1, 1),
-          ("l2 64->128 s2", 256, 64, 32, 128, 3, 2, 1)]
+          ("l2 64->128 s2", 256, 64, 32, 128, 3, 2, 1), ("l3 ds 1x1 s2", 256, 128, 16, 256, 1, 2, 0),
+          ("ddpm 1x1 256 @16", 128, 256, 16, 256, 1, 1, 0), ("ddpm 128->128 @32", 128, 128, 32, 128, 3, 1, 1)]
 
 
 def main():

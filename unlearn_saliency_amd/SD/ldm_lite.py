@@ -57,6 +57,23 @@ class LatentDiffusionLite(nn.Module):
         from ..conv import use_salun_convs
         return use_salun_convs(self.model.diffusion_model)
 
+    def fill_zero_initialised(self, std: float = 0.02, seed: int = 11) -> int:
+        """Benchmarks / full-size tests only (no checkpoint offline): the reference's `zero_module` layers (each
+        ResBlock's last convolution, every transformer's `proj_out`, the output convolution) and all biases start at
+        exactly zero, so a freshly constructed U-Net back-propagates zero gradients to everything in front of its last
+        layer and multiplies by zeros throughout — not what a trained checkpoint does, and zero operands also let the
+        chip clock higher (MI355X_MICROARCH.md, DVFS).  Every parameter element that is exactly 0 gets N(0, std)."""
+        from ..flat import FlatArena
+        arena = getattr(self, "_salun_unet_arena", None)
+        if arena is None:
+            arena = FlatArena(self.model.diffusion_model.named_parameters())
+            object.__setattr__(self, "_salun_unet_arena", arena)
+        z = arena.params == 0
+        n = int(z.sum())
+        if n:
+            arena.params[z] = ops.fill_normal(arena.n, seed, 0.0, std)[z]
+        return n
+
     # ---- the calls the scripts make
     def get_input(self, batch, k=None):
         """-> (z, c).  Accepts {"z","c"} (latents + context) or, with encoders attached, {"jpg","txt"}."""

@@ -1124,6 +1124,157 @@ __global__ __launch_bounds__(256) void conv_wgrad_v(const float *__restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward-weight of a 1x1 convolution (round 3): dW[k][c] = sum_{n,p,q} dY[n][k][p][q] * X[n][c][p*S][q*S] — a plain
+// GEMM whose reduction dimension (the pixels) is the contiguous one of BOTH operands.  `conv_wgrad<1, S>` treated it as
+// a 3x3 kernel with one tap: one accumulator per wave, two LDS reads and a slot full of staging per MFMA — 20 TFLOP/s,
+// 9 % of the DDPM step (its attention / shortcut projections) and 3 % of the ResNet step (the downsample convs).
+// Here a workgroup owns 128 k x 128 c, a wave 64 x 64 (2 x 2 MFMA tiles: four reads feed four MFMAs per pixel pair),
+// both operand tiles are staged as [row][64 pixels (+1)] straight from 16-byte loads along the pixels, double
+// buffered, the next chunk's 16 loads and 64 dword stores dealt out one per MFMA slot as in conv_wgrad_v.
+// grid = (ceil(K/128), ceil(C/128), nsplit); partials [split][k][c] -> conv_wgrad_reduce (RS = 1).
+//   requires: P*Q a multiple of 4, and of 64 or a divisor of 64; Q a multiple of 4 for STRIDE 2 (H = 2P, W = 2Q).
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv_wgrad_1x1(const float *__restrict__ x, const float *__restrict__ dy,
+                                                      float *__restrict__ part, int N, int C, int H, int W, int K,
+                                                      int P, int Q, int nchunks) {
+  constexpr int PIXC = 64, DROW = PIXC + 1, NSTEP = PIXC / 2, HALF = NSTEP / 2;
+  constexpr int NA = 128 * PIXC / 4 / 256;        // float4 items of dY per thread and chunk (8)
+  constexpr int NB = NA;                          // ... of x (each made of STRIDE loads)
+  constexpr int NLD = NA + NB * STRIDE;           // load instructions per thread and chunk (16 / 24)
+  constexpr int LPS = (NLD + HALF - 1) / HALF;    // per step of the first half
+  constexpr int NST = 4 * (NA + NB);              // dword stores per thread and chunk (64)
+  constexpr int SPS = (NST + HALF - 1) / HALF;    // per step of the second half (4)
+  static_assert(LPS <= 4 && SPS <= 4, "one staging instruction per MFMA slot");
+  constexpr int BUF = 2 * 128 * DROW;             // floats per LDS buffer: A tile then B tile
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int kt = wave & 1, ct = wave >> 1;
+  const int k0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  const int split = blockIdx.z, nsplit = gridDim.z;
+  const int PQ = P * Q, HW = H * W;
+  const int per_img = PQ >= PIXC ? PQ / PIXC : 1;   // chunks per image ...
+  const int NI = PQ >= PIXC ? 1 : PIXC / PQ;        // ... or images per chunk
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[t][u][v] = 0.f;
+
+  // ---- staging items (chunk independent part): item i covers row i_row, pixels i_m .. i_m+3 of the chunk
+  int i_lds[NA], i_dn[NA], i_pq[NA], i_row[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int e = tid + i * 256;
+    const int row = e >> 4, m = (e & 15) * 4;
+    i_row[i] = row;
+    i_lds[i] = row * DROW + m;
+    i_dn[i] = NI > 1 ? m / PQ : 0;          // image inside the chunk
+    i_pq[i] = NI > 1 ? m % PQ : m;          // pixel inside that image (+ the chunk's first pixel when NI == 1)
+  }
+  float4 areg[NA], breg[NB * STRIDE];
+  unsigned aoff[NA], amask[NA], boff[NB], bmask[NB];
+  const float *abase = dy, *bbase = x;
+  auto aim = [&](int chunk) {
+    const int n0 = NI > 1 ? chunk * NI : chunk / per_img;
+    const int m0 = NI > 1 ? 0 : (chunk - n0 * per_img) * PIXC;
+    abase = dy + ((size_t)n0 * K + k0) * PQ;
+    bbase = x + ((size_t)n0 * C + c0) * HW;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int n = n0 + i_dn[i], pq = m0 + i_pq[i];
+      const bool oka = n < N && (k0 + i_row[i]) < K;
+      aoff[i] = oka ? (unsigned)((i_dn[i] * K + i_row[i]) * PQ + pq) : 0u;
+      amask[i] = oka ? 0xffffffffu : 0u;
+      const bool okb = n < N && (c0 + i_row[i]) < C;
+      const int p = pq / Q, q = pq - p * Q;  // STRIDE 2: the 4 output pixels q..q+3 read input columns 2q .. 2q+6
+      const int xin = STRIDE == 1 ? pq : (p * STRIDE) * W + q * STRIDE;
+      boff[i] = okb ? (unsigned)((i_dn[i] * C + i_row[i]) * HW + xin) : 0u;
+      bmask[i] = okb ? 0xffffffffu : 0u;
+    }
+  };
+  auto load_item = [&](int li) {
+    if (li < NA) areg[li] = *reinterpret_cast<const float4 *>(abase + aoff[li]);
+    else {
+      const int j = li - NA, i = j / STRIDE, half = j % STRIDE;
+      breg[j] = *reinterpret_cast<const float4 *>(bbase + boff[i] + 4 * half);
+    }
+  };
+  auto comp_of = [](const float4 &v, int comp) { return comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w; };
+  auto store_item = [&](float *buf, int si) {
+    if (si < 4 * NA) {
+      const int i = si >> 2, comp = si & 3;
+      buf[i_lds[i] + comp] = __uint_as_float(__float_as_uint(comp_of(areg[i], comp)) & amask[i]);
+    } else {
+      const int sb = si - 4 * NA, i = sb >> 2, comp = sb & 3;
+      // STRIDE 2: output pixel q + comp reads input column 2 (q + comp): components x, z of the two loads
+      const float v = STRIDE == 1 ? comp_of(breg[i], comp) : comp_of(breg[i * 2 + (comp >> 1)], (comp & 1) * 2);
+      (buf + 128 * DROW)[i_lds[i] + comp] = __uint_as_float(__float_as_uint(v) & bmask[i]);
+    }
+  };
+
+  if (split < nchunks) {
+    aim(split);
+#pragma unroll
+    for (int li = 0; li < NLD; ++li) load_item(li);
+#pragma unroll
+    for (int si = 0; si < NST; ++si) store_item(lds, si);
+    __syncthreads();
+    int cur = 0;
+    for (int chunk = split; chunk < nchunks; chunk += nsplit) {
+      const float *al = lds + cur * BUF;
+      const float *bl = al + 128 * DROW;
+      float *buf_n = lds + (cur ^ 1) * BUF;
+      aim(chunk + nsplit < nchunks ? chunk + nsplit : chunk);  // the last chunk re-stages itself: branch-free body
+      const float *arow = al + (kt * 64 + lo) * DROW + hi;
+      const float *brow = bl + (ct * 64 + lo) * DROW + hi;
+      float a_cur[2], b_cur[2], a_nxt[2] = {0.f, 0.f}, b_nxt[2] = {0.f, 0.f};
+      a_cur[0] = arow[0]; a_cur[1] = arow[32 * DROW];
+      b_cur[0] = brow[0]; b_cur[1] = brow[32 * DROW];
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          const int t = sl >> 1, u = sl & 1;
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur[u], acc[t][u], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < NSTEP) {  // one operand of the next pixel pair per slot
+            if (sl < 2) a_nxt[sl] = arow[sl * 32 * DROW + 2 * st + 2];
+            else b_nxt[sl - 2] = brow[(sl - 2) * 32 * DROW + 2 * st + 2];
+          }
+          if (st < HALF) {
+            if (sl < LPS && st * LPS + sl < NLD) load_item(st * LPS + sl);
+          } else {
+            if (sl < SPS && (st - HALF) * SPS + sl < NST) store_item(buf_n, (st - HALF) * SPS + sl);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
+        b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float *out = part + (size_t)split * K * C;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = c0 + ct * 64 + u * 32 + lo;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = k0 + kt * 64 + t * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+        if (k < K && c < C) out[(size_t)k * C + c] = acc[t][u][v];
+      }
+    }
+}
+
 // backward-weight for tiny input-channel counts (the RGB stem: C*R*R <= 32).  The general kernel would spend a
 // 64-channel tile and R*R accumulators on 3 real channels; here the 32 MFMA columns are the (c, r, s) combinations
 // themselves (27 for RGB 3x3), one accumulator per wave, and the kernel is bound by reading dY once.
@@ -1582,6 +1733,20 @@ int launch_dgrad(const float *dy, const float *w, const float *addend, float *dx
   return SALUN_OK;
 }
 
+// 1x1 backward-weight (conv_wgrad_1x1): geometry and split count; 0 chunks = shape outside its domain
+inline int wgrad1x1_chunks(int N, int P, int Q, int stride) {
+  const int PQ = P * Q;
+  if (PQ % 4 != 0 || (stride == 2 && Q % 4 != 0)) return 0;
+  if (PQ >= 64) return (PQ % 64 == 0) ? N * (PQ / 64) : 0;
+  return (64 % PQ == 0) ? (N + 64 / PQ - 1) / (64 / PQ) : 0;
+}
+inline int wgrad1x1_nsplit(int K, int C, int nchunks) {
+  const int tiles = ((K + 127) / 128) * ((C + 127) / 128);
+  int ns = (256 + tiles - 1) / tiles;
+  if (ns > nchunks) ns = nchunks;
+  return ns < 1 ? 1 : ns;
+}
+
 inline int wgrad_nsplit(int K, int C, int nchunks) {
   const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
   // one workgroup per CU is resident (register budget): a single full round of 256 workgroups, each with a long
@@ -1641,6 +1806,10 @@ SALUN_EXPORT size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int 
     if (nss > nt) nss = nt;
     if (nss * 2 > ns) ns = nss * 2;
   }
+  if (R == 1) {  // conv_wgrad_1x1 splits deeper (128 x 128 tiles): size for whichever kernel the shape gets
+    const int nc1 = wgrad1x1_chunks(N, P, Q, 1);
+    if (nc1 > 0) { const int ns1 = wgrad1x1_nsplit(K, C, nc1); if (ns1 > ns) ns = ns1; }
+  }
   return sizeof(float) * (size_t)ns * K * C * R * R;
 }
 
@@ -1650,6 +1819,29 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
                                               void *ws, size_t ws_bytes, salun_stream_t stream) {
   if (!x || !dy || !dw || !ws || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
   if (!((R == 3 || R == 1) && (stride == 1 || stride == 2))) return SALUN_EINVAL;
+  if (R == 1 && pad == 0 && C >= 32 && H == P * stride && W == Q * stride && W % 4 == 0 && salun_aligned16(x) &&
+      salun_aligned16(dy) && (size_t)64 * C * H * W < (1u << 30) && (size_t)64 * K * P * Q < (1u << 30)) {
+    const int nc1 = wgrad1x1_chunks(N, P, Q, stride);
+    if (nc1 > 0) {  // GEMM-shaped 1x1 kernel
+      hipStream_t st1 = salun_hip_stream(stream);
+      const int ns1 = wgrad1x1_nsplit(K, C, nc1);
+      if (ws_bytes < sizeof(float) * (size_t)ns1 * K * C) return SALUN_ENOSPC;
+      const size_t lds1 = sizeof(float) * 2 * 2 * 128 * 65;
+      dim3 grid1((K + 127) / 128, (C + 127) / 128, ns1);
+      float *part1 = static_cast<float *>(ws);
+      if (stride == 1) {
+        allow_lds(conv_wgrad_1x1<1>, lds1);
+        hipLaunchKernelGGL(conv_wgrad_1x1<1>, grid1, dim3(256), lds1, st1, x, dy, part1, N, C, H, W, K, P, Q, nc1);
+      } else {
+        allow_lds(conv_wgrad_1x1<2>, lds1);
+        hipLaunchKernelGGL(conv_wgrad_1x1<2>, grid1, dim3(256), lds1, st1, x, dy, part1, N, C, H, W, K, P, Q, nc1);
+      }
+      SALUN_LAUNCH_CHECK();
+      launch_wgrad_reduce(part1, dw, (int64_t)K * C, ns1, accumulate, K * C, 1, st1);
+      SALUN_LAUNCH_CHECK();
+      return SALUN_OK;
+    }
+  }
   const int pixc = (stride == 1) ? 64 : 32;
   TileGeom g = make_geom(N, P, Q, pixc, stride, R);
   if (!g.ok || g.NI * g.IH_t * g.IW_t > 256) return SALUN_EINVAL;

@@ -101,13 +101,18 @@ int salun_mask_topk(const float *acc /*dev*/, int64_t n, const int64_t *ks /*hos
 int salun_mask_topk_ex(const float *acc /*dev*/, int64_t n, const int64_t *ks /*host*/,
                        int nk, uint8_t *const *masks_out /*host array of dev ptrs, or NULL*/,
                        void *ws /*dev*/, size_t ws_bytes, unsigned flags, salun_stream_t stream);
-/* Diagnostic (synchronises the stream): which route finished the last call on this ws
- * (1 = single-read, 2 = full scan) and whether a grid barrier of the full scan timed out. */
+/* Synchronises the stream: which route finished the last call on this ws (1 = single-read, 2 = full scan) and
+ * whether a grid barrier of the full scan timed out (*error_out = 1: the masks / thresholds of that call are INVALID).
+ * The full scan synchronises its workgroups with a bounded software grid barrier; called directly (small or
+ * unaligned inputs, SALUN_TOPK_FORCE_FULL_SCAN) it is launched cooperatively, so the runtime guarantees the
+ * co-residency the barrier needs; as the fallback behind the single-read route it is a plain launch.  Either way a
+ * time-out is never silent: callers that hand masks to a file or an optimizer check this status (one host sync, the
+ * Python wrappers' `check=True`), callers that must not synchronise receive NaN from salun_mask_topk_thresholds. */
 int salun_mask_topk_status(const void *ws /*dev*/, int *route_out /*host*/, int *error_out /*host*/,
                            salun_stream_t stream);
 /* After salun_mask_topk on the same ws: copies the nk selected thresholds
- * (as fp32 |acc| values; NaN if the k-th element is a NaN; +inf for k <= 0, -1 for
- * k > n) to a device array, 4*nk bytes.  Used by the proximal step (K9) as the
+ * (as fp32 |acc| values; NaN if the k-th element is a NaN OR if the select failed — see salun_mask_topk_status;
+ * +inf for k <= 0, -1 for k > n) to a device array, 4*nk bytes.  Used by the proximal step (K9) as the
  * device-resident threshold. */
 int salun_mask_topk_thresholds(const void *ws /*dev*/, int nk, float *tau_out /*dev*/,
                                salun_stream_t stream);
@@ -297,7 +302,9 @@ int salun_gn_bf16_backward(const uint16_t *dy /*dev*/, const uint16_t *x /*dev*/
  * cross-attention (77 text tokens), 8 heads of D = 40 / 80 / 160 channels (D in {8,16,32,40,64,80,160} supported).
  * Tensors are [B, tokens, H, D] VIEWS: element (b, t, h, d) at b*bs + t*ld + h*D + d (elements); every (token, head)
  * row must be 16-byte aligned.  `lse` ([B*H][Nq] fp32, log2-domain logsumexp of the scaled scores) is the forward's
- * second output and the backward's input; `dsum` is [B*H][Nq] fp32 scratch; dq / dk / dv are written contiguous. */
+ * second output and the backward's input; `dsum` is [B*H][Nq] fp32 scratch; dq / dk / dv are written contiguous.
+ * `scale` must be positive and finite (SALUN_EINVAL otherwise): the kernels take the running maximum on the raw
+ * scores and apply scale*log2(e) afterwards; every attention of the three models uses 1/sqrt(D). */
 int salun_attn_supported(int D);
 int salun_attn_forward(const uint16_t *q /*dev*/, const uint16_t *k /*dev*/, const uint16_t *v /*dev*/, uint16_t *o /*dev*/,
                        float *lse /*dev or NULL*/, int B, int H, int Nq, int Nk, int D, long long q_bs, int q_ld,
@@ -380,7 +387,9 @@ int salun_gn_backward(const float *dz /*dev*/, const float *x /*dev*/, const flo
  * as three launches on the flat vectors:  salun_param_diff (out = p - p0, 12 B/elem)  ->  salun_mask_topk on `out`
  * with k = n - ratio + 1 (its k-th largest |d| IS the ratio-th smallest; threshold fetched on the device with
  * salun_mask_topk_thresholds)  ->  salun_soft_threshold_step (12 B/elem), which reads the threshold from device
- * memory — no host round trip.  fp32 arithmetic identical to the reference's tensor expressions. */
+ * memory — no host round trip.  fp32 arithmetic identical to the reference's tensor expressions.
+ * A NaN threshold (a failed select) is propagated: every element of `p` becomes NaN, so the next loss is NaN — never
+ * the silent "all weights reset to p0" the three-way comparison would otherwise produce. */
 int salun_param_diff(const float *p /*dev*/, const float *p0 /*dev*/, float *out /*dev*/, int64_t n,
                      salun_stream_t stream);
 int salun_soft_threshold_step(float *p /*dev*/, const float *p0 /*dev*/, const float *tau /*dev, 1 float*/,

@@ -78,10 +78,13 @@ struct PatchPos {
 //   KT       32-channel output tiles per wave
 //   WP x WK  wave grid inside the workgroup: WP pixel tiles x WK channel groups (WP*WK == 4)
 //   DGRAD    backward-data mode
+//   PT       32-pixel tiles per wave (round 3: PT = 2 for the 64-channel layers — a wave then owns 64 pixels x 64
+//            channels, four MFMAs per four operand reads instead of two per three, and the weight slab of a chunk is
+//            staged once per 256 pixels instead of once per 128)
 // `x` is the tensor the patch is read from (forward: input; DGRAD: dY), `y` the tensor written.
 // `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
 // STRIDE and the padding is R-1-pad.
-template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST>
+template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST, int PT = 1>
 __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
                                                   const float *__restrict__ bias, float *__restrict__ y, int N,
                                                   int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
@@ -109,12 +112,17 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
   if (NI > 1) { n0 = tile * NI; p0 = 0; }
   else { n0 = tile / tiles_per_img; p0 = (tile - n0 * tiles_per_img) * TP; }
 
-  // ---- this lane's output pixel inside the tile (fixed for the whole kernel)
-  const int mloc = wp * 32 + lo;               // 0 .. WP*32-1: pixel inside the workgroup tile
-  const int q_l = mloc & (Q - 1);
-  const int pr = mloc >> logQ;                 // row index inside the tile (over NI*TP rows)
-  const int ni_l = pr / TP, p_l = pr - ni_l * TP;
-  const int pix_off = (ni_l * IH_t + p_l * CONV_S) * IW_t + q_l * CONV_S;  // tap (0,0) position in the patch
+  // ---- this lane's output pixels inside the tile (fixed for the whole kernel), one per pixel tile of the wave
+  int q_l[PT], ni_l[PT], p_l[PT], pix_off[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int mloc = (wp * PT + pt) * 32 + lo;  // 0 .. WP*PT*32-1: pixel inside the workgroup tile
+    q_l[pt] = mloc & (Q - 1);
+    const int pr = mloc >> logQ;               // row index inside the tile (over NI*TP rows)
+    ni_l[pt] = pr / TP;
+    p_l[pt] = pr - ni_l[pt] * TP;
+    pix_off[pt] = (ni_l[pt] * IH_t + p_l[pt] * CONV_S) * IW_t + q_l[pt] * CONV_S;  // tap (0,0) position in the patch
+  }
 
   // ---- the (<= 3) patch positions this thread stages for every channel of a chunk
   constexpr int MAXPOS = 3;
@@ -148,11 +156,13 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
     }
   }
 
-  f32x16 acc[KT];
+  f32x16 acc[PT][KT];
 #pragma unroll
-  for (int t = 0; t < KT; ++t)
+  for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[pt][t][v] = 0.f;
 
   const int Cred = xC;  // reduction channels = channels of the tensor the patch is read from
   // Register-staged software pipeline: the global loads of chunk i+1 are issued before the MFMA section of
@@ -274,44 +284,54 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
     // The (1 + KT) LDS operands of k-step i+1 are read while the KT MFMAs of k-step i run (one-step-ahead
     // software pipeline, pinned with scheduling barriers): no MFMA waits for an LDS round trip.
     constexpr int NSTEP = (CC / 2) * RS;
-    const float *pb0 = patch + hi * ch_stride + pix_off;
+    const float *pb0 = patch + hi * ch_stride;
     const float *wb0 = wl + (wk * KT * 32 + lo) * WROW + hi * RS;
-    auto operands = [&](int step, float &bv, float (&av)[KT]) {
+    auto operands = [&](int step, float (&bv)[PT], float (&av)[KT]) {
       const int cc = 2 * (step / RS), rs = step % RS, r = rs / R, s2 = rs % R;  // compile-time after unrolling
-      bv = pb0[cc * ch_stride + r * IW_t + s2];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) bv[pt] = pb0[pix_off[pt] + cc * ch_stride + r * IW_t + s2];
 #pragma unroll
       for (int t = 0; t < KT; ++t) av[t] = wb0[t * 32 * WROW + cc * RS + rs];
     };
-    float b_cur, a_cur[KT], b_nxt = 0.f, a_nxt[KT];
+    float b_cur[PT], a_cur[KT], b_nxt[PT], a_nxt[KT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) b_nxt[pt] = 0.f;
     operands(0, b_cur, a_cur);
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
       if (step + 1 < NSTEP) operands(step + 1, b_nxt, a_nxt);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur, acc[t], 0, 0, 0);
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+          acc[pt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur[pt], acc[pt][t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      b_cur = b_nxt;
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) b_cur[pt] = b_nxt[pt];
 #pragma unroll
       for (int t = 0; t < KT; ++t) a_cur[t] = a_nxt[t];
     }
   }
 
   // ---- epilogue: D[row = channel][col = pixel]; row = (v&3) + 8*(v>>2) + 4*hi
-  const int n_out = n0 + ni_l, p_out = p0 + p_l;
   if ((SALUN_IGEMM_EXP & 8) && N > 0) return;
-  if (n_out < N) {
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      const int kbase = k0 + (wk * KT + t) * 32;
+  for (int pt = 0; pt < PT; ++pt) {
+    const int n_out = n0 + ni_l[pt], p_out = p0 + p_l[pt];
+    if (n_out < N) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
-        if (k < yC) {
-          float o = acc[t][v];
-          const size_t oi = (((size_t)n_out * yC + k) * P + p_out) * Q + q_l;
-          if (bias) o += DGRAD ? bias[oi] : bias[k];  // backward-data: `bias` is a full-size addend (may alias y)
-          y[oi] = o;
+      for (int t = 0; t < KT; ++t) {
+        const int kbase = k0 + (wk * KT + t) * 32;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
+          if (k < yC) {
+            float o = acc[pt][t][v];
+            const size_t oi = (((size_t)n_out * yC + k) * P + p_out) * Q + q_l[pt];
+            if (bias) o += DGRAD ? bias[oi] : bias[k];  // backward-data: `bias` is a full-size addend (may alias y)
+            y[oi] = o;
+          }
         }
       }
     }
@@ -1564,7 +1584,22 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
   }
   if (pixt == 128) {
     if (yC > 64) SALUN_IGEMM(4, 4, 1)
-    else if (yC > 32) SALUN_IGEMM(2, 4, 1)
+    else if (yC > 32) {
+      // 64 output channels: a wave takes 64 pixels x 64 channels (PT = 2) when 256-pixel tiles still fill the chip
+      // and the stride-1 fast path applies
+      TileGeom g256 = make_geom(N, yH, yW, 256, cs, R);
+      const int ps256 = g256.ok ? g256.NI * g256.IH_t * g256.IW_t : 0;
+      const bool fast2 = (xC % CC == 0) && (!DGRAD || yC % 64 == 0) && salun_aligned16(w) && ((wC * RS) % 4 == 0) &&
+                         !(DGRAD && STRIDE > 1);
+      if (g256.ok && fast2 && g256.ntiles >= 512 && ps256 <= 768) {
+        const int chs = ps256 | 1;
+        const size_t ldsb2 = sizeof(float) * ((size_t)CC * chs + (size_t)64 * (CC * RS + 1));
+        dim3 grid2(g256.ntiles, (yC + 63) / 64);
+        allow_lds(conv_igemm<R, STRIDE, 2, 4, 1, DGRAD, true, 2>, ldsb2);
+        hipLaunchKernelGGL((conv_igemm<R, STRIDE, 2, 4, 1, DGRAD, true, 2>), grid2, dim3(256), ldsb2, st, x, w, bias, y,
+                           N, xC, xH, xW, yC, yH, yW, pad, g256.NI, g256.TP, g256.IH_t, g256.IW_t, g256.logQ, wC, wK);
+      } else SALUN_IGEMM(2, 4, 1)
+    }
     else SALUN_IGEMM(1, 4, 1)
   } else {
     // small pixel space (deep layers): 64 x 128 tiles only if that still yields enough workgroups

@@ -236,6 +236,13 @@ int salun_conv2d_backward_data(const float *dy /*dev*/, const float *w /*dev*/, 
 int salun_conv2d_backward_data_add(const float *dy /*dev*/, const float *w /*dev*/, const float *addend /*dev or NULL*/,
                                    float *dx /*dev*/, int N, int C, int H, int W, int K, int R, int stride, int pad,
                                    int P, int Q, salun_stream_t stream);
+/* Bias gradient of a convolution: out[k] (= or +=, `accumulate`) sum over n, p, q of dy[n][k][p][q] — what the reference
+ * gets from autograd's `sum(dim=(0, 2, 3))` + AccumulateGrad for every biased `nn.Conv2d` of the diffusion U-Nets
+ * (DDPM/models/diffusion.py:20-75, SD openaimodel.py `conv_nd`).  One streaming pass, 4 B per element of dy;
+ * deterministic (fixed-order partial sums).  `out` may be the parameter's slice of the flat gradient arena. */
+size_t salun_channel_sum_workspace_bytes(int N, int K);
+int salun_channel_sum(const float *dy /*dev*/, float *out /*dev, K floats*/, int N, int K, int HW, int accumulate,
+                      void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int R, int P, int Q);
 int salun_conv2d_backward_weight(const float *x /*dev*/, const float *dy /*dev*/, float *dw /*dev*/, int N, int C,
                                  int H, int W, int K, int R, int stride, int pad, int P, int Q, int accumulate,

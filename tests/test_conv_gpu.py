@@ -119,3 +119,46 @@ def test_module_swap_resnet18_forward_backward():
     print(f"worst gradient error relative to tensor scale vs float64: mfma {worst:.3e}, library {worst_lib:.3e}")
     # fp32 round-off through 20 train-mode BN layers dominates both; the MFMA path must be no worse than the library's
     assert worst < 3 * worst_lib + 1e-5
+
+
+@pytest.mark.parametrize("N,K,H", [(128, 128, 32), (5, 3, 16), (8, 200, 4), (2, 40, 7), (300, 64, 8)])
+def test_channel_sum_is_the_bias_gradient(N, K, H):
+    """`salun_channel_sum` (the conv-bias gradient, round 3) vs a float64 sum on the host; accumulate adds in place;
+    deterministic.  Tolerance 2e-6 of the sum of |dy| per channel (fp32 partial sums in a fixed tree)."""
+    from unlearn_saliency_amd import ops
+    dy = _rand((N, K, H, H), 9)
+    ref = dy.double().sum(dim=(0, 2, 3))
+    scale = dy.double().abs().sum(dim=(0, 2, 3))
+    d = dy.cuda()
+    got = ops.channel_sum(d)
+    assert got.shape == (K,) and torch.all((got.cpu().double() - ref).abs() <= 2e-6 * scale)
+    assert torch.equal(got, ops.channel_sum(d))
+    base = _rand((K,), 10).cuda()
+    acc = base.clone()
+    ops.channel_sum(d, out=acc, accumulate=True)
+    assert torch.equal(acc, base + got)
+    view = d[:, :, :, :].permute(0, 1, 2, 3)[:, :, 1:, :]  # odd offset: 16-byte alignment lost -> scalar path
+    if H > 1:
+        v = view.contiguous()
+        assert torch.allclose(ops.channel_sum(v).cpu().double(), v.cpu().double().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-4)
+
+
+def test_conv_bias_gradient_lands_in_the_flat_arena_without_autograd_adds():
+    """A biased SalunConv2d inside a FlatArena: after backward, bias.grad (a view of the flat gradient) holds the
+    channel sums of dy, accumulated over two backward passes, and equals the library module's bias gradient."""
+    import copy
+    from unlearn_saliency_amd.conv import use_salun_convs
+    from unlearn_saliency_amd.flat import arena_of
+    torch.manual_seed(4)
+    lib = torch.nn.Sequential(torch.nn.Conv2d(32, 64, 3, padding=1), torch.nn.SiLU(), torch.nn.Conv2d(64, 32, 1)).cuda()
+    own = copy.deepcopy(lib)
+    assert use_salun_convs(own) == 2
+    arena = arena_of(own)
+    x = torch.randn(8, 32, 16, 16, device="cuda")
+    arena.zero_grad()
+    for _ in range(2):
+        own(x).square().mean().backward()
+        lib(x).square().mean().backward()
+    assert own[0].bias.grad.data_ptr() == arena.grads[arena.offsets[1]:].data_ptr()
+    for a, b in zip(own.parameters(), lib.parameters()):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6 * float(b.grad.abs().max())), a.shape

@@ -62,6 +62,7 @@ class _ConvFn(torch.autograd.Function):
             ctx.native = True
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, bias is not None
+        ctx.bias_param = bias  # only looked at for its .grad destination (gradsink), never read as a value
         return y
 
     @staticmethod
@@ -100,7 +101,14 @@ class _ConvFn(torch.autograd.Function):
                 _fallback("backward", f"backward-data {tuple(x.shape)} * {tuple(w.shape)}")
                 dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=(0, 2, 3))
+            # own streaming kernel instead of ATen's generic reduction; added straight into bias.grad when that is a
+            # plain view of the flat arena (no AccumulateGrad launch)
+            bdst = gradsink.sink(ctx.bias_param)
+            if bdst is not None:
+                ops.channel_sum(dy, out=bdst, accumulate=True)
+                gradsink.arrived(ctx.bias_param)
+            else:
+                db = ops.channel_sum(dy)
         return dx, dw, db, None, None, None, None
 
 

@@ -309,6 +309,19 @@ def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: i
     return dw
 
 
+def channel_sum(dy: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """Bias gradient of a convolution: sum of dy[N, K, P, Q] over n, p, q -> [K] (written, or added into `out`)."""
+    N, K = dy.shape[0], dy.shape[1]
+    HW = dy.shape[2] * dy.shape[3]
+    L = _lib.lib()
+    ws = workspace(L.salun_channel_sum_workspace_bytes(N, K), dy.device)
+    res = out if out is not None else torch.empty(K, dtype=torch.float32, device=dy.device)
+    check(L.salun_channel_sum(_dev(dy, torch.float32, "dy"), _dev(res, torch.float32, "out"), N, K, HW,
+                              int(bool(accumulate and out is not None)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()),
+                              _stream()), "salun_channel_sum")
+    return res
+
+
 # ----------------------------------------------------------------------------- K11
 # bf16 NHWC convolution on the bf16 matrix-core instruction; tensors are [N, H, W, C] contiguous bfloat16.
 def conv2d_bf16_supported(C: int, K: int, R: int, stride: int, pad: int) -> bool:

@@ -14,6 +14,8 @@ torch.backends.cudnn.deterministic = False
 torch.backends.cudnn.benchmark = True
 if "--lib" not in sys.argv:
     use_salun_convs(model)
+    from unlearn_saliency_amd.norm import use_fused_bn
+    use_fused_bn(model)
 arena = arena_of(model)
 opt = FusedMaskedSGD(arena, 0.013, 0.9, 5e-4)
 opt.set_mask(ops.mask_topk(ops.fill_normal(arena.n, 5, 0, 1e-3), [arena.n // 2])[0])

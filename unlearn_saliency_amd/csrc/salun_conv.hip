@@ -48,6 +48,15 @@ constexpr int CC = 8;  // reduction channels staged per chunk
 #ifndef SALUN_IGEMM_EXP
 #define SALUN_IGEMM_EXP 0
 #endif
+// 1 = 3x3 backward-weight on the eight-wave kernel (two waves per SIMD, conv_wgrad_w) where its geometry applies.
+// Measured (round 3, MI355X): ALONE it is 3-7 % faster than conv_wgrad_v (197 vs 204 us on 64x64 @32, 322 vs 347 us on
+// the DDPM's 128x128 @32), but INSIDE the step, where backward-weight shares every CU with backward-data of the main
+// stream, its second wave per SIMD takes issue slots and registers from that kernel and the step gets slower
+// (ResNet-18 112.4 vs 116.3 steps/s, DDPM 8.22 vs 8.31; stream priorities change nothing) — so the product keeps
+// the four-wave kernel and this one stays as a build option.
+#ifndef SALUN_WGRAD_8WAVES
+#define SALUN_WGRAD_8WAVES 0
+#endif
 
 struct ConvGeomUnused {
   // logical convolution: out[n][k][p][q] = sum x[n][c][p*S - pad + r][q*S - pad + s] * w[k][c][r][s]
@@ -1145,6 +1154,201 @@ __global__ __launch_bounds__(256) void conv_wgrad_v(const float *__restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// backward-weight, 3x3, TWO waves per SIMD (round 3).  `conv_wgrad_v` keeps nine accumulators (144 registers) per wave,
+// so one wave owns a SIMD and every LDS-latency hiccup of its single instruction stream idles the matrix pipe (its bare
+// MFMA + operand-read loop runs at 108-111 TFLOP/s where the two-waves-per-SIMD `conv_igemm` loop reaches 135-141).
+// Here the workgroup has EIGHT waves: waves 0-3 take taps 0-4, waves 4-7 taps 5-8 of the same four 32 k x 32 c
+// quadrants (5 / 4 accumulators = 80 / 64 registers), so every SIMD carries one wave of each group — nine MFMAs per
+// pixel pair per SIMD as before, issued by two independent streams; the dY operand is read by both (11 LDS reads per
+// 9 MFMAs instead of 10).  Staging is `conv_wgrad_v`'s, dealt over 512 threads (half the instructions per thread).
+// Same LDS image, same partial-sum layout, same summation order per accumulator => bit-identical results.
+template <int STRIDE, int NIT, int NTAP, int TBASE>
+__device__ __forceinline__ void wgrad_w_body(const float *__restrict__ x, const float *__restrict__ dy,
+                                             float *__restrict__ part, int N, int C, int H, int W, int K, int P, int Q,
+                                             int NI, int TP, int IH_t, int IW_t, int logQ, int nchunks, float *lds) {
+  constexpr int R = 3, RS = 9, PAD = 1;
+  constexpr int PIXC = (STRIDE == 1) ? 64 : 32;
+  constexpr int DROW = PIXC + 1;
+  constexpr int NSTEP = PIXC / 2;
+  constexpr int HALF = NSTEP / 2;
+  constexpr int DN4 = 64 * PIXC / 4 / 512;       // float4 items of dy per thread and chunk (2 or 1)
+  constexpr int LOGPIX4 = (PIXC == 64) ? 4 : 3;
+  constexpr int NLD = NIT + DN4;
+  constexpr int LPS = (NLD + HALF - 1) / HALF;
+  constexpr int NST = 4 * (NIT + DN4);
+  constexpr int SPS = (NST + HALF - 1) / HALF;
+  static_assert(LPS <= 4 && SPS <= 4, "one staging instruction per MFMA slot at most (4 slots in the short group)");
+  const int PSZ = NI * IH_t * IW_t;
+  const int ch_stride = PSZ | 1;
+  const int BUF = 64 * ch_stride + 64 * DROW + 512;  // x patch + dy tile + dump row (items beyond the patch)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wq = wave & 3, kt = wq & 1, ct = wq >> 1;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int split = blockIdx.z, nsplit = gridDim.z;
+  const int tiles_per_img = (NI > 1) ? 1 : P / TP;
+  const int planeHW = H * W, PQ = P * Q;
+  const int logTP = __builtin_ctz(TP);
+  const int W4 = W >> 2;
+  const int F4C = NI * IH_t * W4;
+
+  f32x16 acc[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  int it_lds[NIT], it_g[NIT], it_ih[NIT], it_ni[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int e = tid + k * 512;
+    const bool real = e < 64 * F4C;              // the last item of a thread may fall beyond the patch
+    const int ee = real ? e : 0;
+    const int c = ee / F4C, r = ee - c * F4C;
+    const int ni = r / (IH_t * W4), r2 = r - ni * (IH_t * W4);
+    const int ih = r2 / W4, g4 = r2 - ih * W4;
+    it_lds[k] = real ? c * ch_stride + (ni * IH_t + ih) * IW_t + PAD + 4 * g4 : 64 * ch_stride + 64 * DROW + (tid & ~3);
+    it_g[k] = (ni * C + c) * planeHW + (ih - PAD) * W + 4 * g4;
+    it_ih[k] = real ? ih : -(1 << 20);           // never inside the image: loads clamp, stores are masked
+    it_ni[k] = ni;
+  }
+  float4 xreg[NIT];
+  float4 dreg[DN4];
+  const float *xbase = x;
+  unsigned xoff[NIT], xmask[NIT];
+  const float *dbase = dy;
+  unsigned doff[DN4], dmask[DN4];
+  int d_kk[DN4], d_ni[DN4], d_in[DN4];
+#pragma unroll
+  for (int i = 0; i < DN4; ++i) {
+    const int e4 = tid + i * 512;
+    const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4;
+    const int q = m & (Q - 1), pr = m >> logQ;
+    d_kk[i] = kk;
+    d_ni[i] = pr >> logTP;
+    d_in[i] = (pr & (TP - 1)) * Q + q;
+  }
+  auto aim = [&](int chunk) {
+    int n0, p0;
+    if (NI > 1) { n0 = chunk * NI; p0 = 0; }
+    else { n0 = chunk / tiles_per_img; p0 = (chunk - n0 * tiles_per_img) * TP; }
+    xbase = x + ((size_t)n0 * C + c0) * planeHW;
+    const int h0 = p0 * STRIDE;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int h = h0 - PAD + it_ih[k];
+      const bool ok = (n0 + it_ni[k]) < N && h >= 0 && h < H;
+      xoff[k] = ok ? (unsigned)(it_g[k] + h0 * W) : 0u;
+      xmask[k] = ok ? 0xffffffffu : 0u;
+    }
+    dbase = dy + ((size_t)n0 * K + k0) * PQ + (size_t)p0 * Q;
+#pragma unroll
+    for (int i = 0; i < DN4; ++i) {
+      const bool okd = (n0 + d_ni[i]) < N && (k0 + d_kk[i]) < K;
+      doff[i] = okd ? (unsigned)((d_ni[i] * K + d_kk[i]) * PQ + d_in[i]) : 0u;
+      dmask[i] = okd ? 0xffffffffu : 0u;
+    }
+  };
+  auto load_item = [&](int li) {
+    if (li < NIT) xreg[li] = *reinterpret_cast<const float4 *>(xbase + xoff[li]);
+    else dreg[li - NIT] = *reinterpret_cast<const float4 *>(dbase + doff[li - NIT]);
+  };
+  auto comp_of = [](const float4 &v, int comp) { return comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w; };
+  auto store_item = [&](float *buf, int si) {
+    if (si < 4 * NIT) {
+      const int k = si >> 2, comp = si & 3;
+      buf[it_lds[k] + comp] = __uint_as_float(__float_as_uint(comp_of(xreg[k], comp)) & xmask[k]);
+    } else {
+      const int sd = si - 4 * NIT, i = sd >> 2, comp = sd & 3;
+      const int e4 = tid + i * 512;
+      const int kk = e4 >> LOGPIX4, m = (e4 & (PIXC / 4 - 1)) * 4 + comp;
+      (buf + 64 * ch_stride)[kk * DROW + m] = __uint_as_float(__float_as_uint(comp_of(dreg[i], comp)) & dmask[i]);
+    }
+  };
+
+  for (int i = tid; i < 2 * BUF; i += 512) lds[i] = 0.f;  // halo columns stay zero for the whole kernel
+  __syncthreads();
+
+  if (split < nchunks) {
+    aim(split);
+#pragma unroll
+    for (int li = 0; li < NLD; ++li) load_item(li);
+#pragma unroll
+    for (int si = 0; si < NST; ++si) store_item(lds, si);
+    __syncthreads();
+
+    int cur = 0;
+    for (int chunk = split; chunk < nchunks; chunk += nsplit) {
+      const float *xp = lds + cur * BUF;
+      const float *dl = xp + 64 * ch_stride;
+      float *buf_n = lds + (cur ^ 1) * BUF;
+      aim(chunk + nsplit < nchunks ? chunk + nsplit : chunk);
+      const float *arow = dl + (kt * 32 + lo) * DROW + hi;
+      const float *brow = xp + (ct * 32 + lo) * ch_stride + hi * STRIDE;
+      auto pair_off = [&](int j) {
+        const int q0 = j & (Q - 1), pr = j >> logQ;
+        const int ni = pr >> logTP, pl = pr & (TP - 1);
+        return (ni * IH_t + pl * STRIDE) * IW_t + q0 * STRIDE;
+      };
+      float a_cur, b_cur[NTAP], a_nxt = 0.f, b_nxt[NTAP];
+      {
+        const float *bp = brow + pair_off(0);
+        a_cur = arow[0];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) b_cur[t] = bp[((TBASE + t) / R) * IW_t + ((TBASE + t) % R)];
+      }
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        const float *bp = brow + ((st + 1 < NSTEP) ? pair_off(2 * st + 2) : 0);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < NSTEP) {
+            if (t == 0) a_nxt = arow[2 * st + 2];
+            b_nxt[t] = bp[((TBASE + t) / R) * IW_t + ((TBASE + t) % R)];
+          }
+          if (st < HALF) {
+            if (t < LPS && st * LPS + t < NLD) load_item(st * LPS + t);
+          } else {
+            if (t < SPS && (st - HALF) * SPS + t < NST) store_item(buf_n, (st - HALF) * SPS + t);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        a_cur = a_nxt;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) b_cur[t] = b_nxt[t];
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float *out = part + (size_t)split * K * C * RS;
+  const int c = c0 + ct * 32 + lo;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int k = k0 + kt * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+      if (k < K) out[((size_t)(TBASE + t) * K + k) * C + c] = acc[t][v];
+    }
+}
+
+template <int STRIDE, int NIT>
+__global__ __launch_bounds__(512) void conv_wgrad_w(const float *__restrict__ x, const float *__restrict__ dy,
+                                                    float *__restrict__ part, int N, int C, int H, int W, int K, int P,
+                                                    int Q, int NI, int TP, int IH_t, int IW_t, int logQ, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // wave-uniform: both groups execute the same number of barriers (one after the clear, one after the prologue, one
+  // per chunk), at different program counters
+  if ((threadIdx.x >> 8) == 0)
+    wgrad_w_body<STRIDE, NIT, 5, 0>(x, dy, part, N, C, H, W, K, P, Q, NI, TP, IH_t, IW_t, logQ, nchunks, lds);
+  else
+    wgrad_w_body<STRIDE, NIT, 4, 5>(x, dy, part, N, C, H, W, K, P, Q, NI, TP, IH_t, IW_t, logQ, nchunks, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward-weight of a 1x1 convolution (round 3): dW[k][c] = sum_{n,p,q} dY[n][k][p][q] * X[n][c][p*S][q*S] — a plain
 // GEMM whose reduction dimension (the pixels) is the contiguous one of BOTH operands.  `conv_wgrad<1, S>` treated it as
 // a 3x3 kernel with one tap: one accumulator per wave, two LDS reads and a slot full of staging per MFMA — 20 TFLOP/s,
@@ -1997,7 +2201,27 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
                        g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles);                                          \
     vec_done = true;                                                                                           \
   }
-    if (stride == 1) {
+#define SALUN_WGRAD_W(S_, NIT_)                                                                                \
+  {                                                                                                            \
+    allow_lds(conv_wgrad_w<S_, NIT_>, ldsw);                                                                   \
+    hipLaunchKernelGGL((conv_wgrad_w<S_, NIT_>), grid, dim3(512), ldsw, st, x, dy, part, N, C, H, W, K, P, Q,  \
+                       g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, g.ntiles);                                          \
+    vec_done = true;                                                                                           \
+  }
+    // eight-wave variant (two waves per SIMD): NIT = ceil(64 * F4C / 512) items per thread
+    const int nitw = (64 * F4C + 511) / 512;
+    const size_t ldsw = sizeof(float) * 2 * ((size_t)64 * (PSZ | 1) + (size_t)64 * (pixc + 1) + 512);
+    if (SALUN_WGRAD_8WAVES && ldsw <= 160 * 1024) {
+      if (stride == 1) {
+        if (nitw == 3) SALUN_WGRAD_W(1, 3)
+        else if (nitw == 4) SALUN_WGRAD_W(1, 4)
+      } else {
+        if (nitw == 5) SALUN_WGRAD_W(2, 5)
+      }
+    }
+#undef SALUN_WGRAD_W
+    if (vec_done) { }
+    else if (stride == 1) {
       if (nit == 5) SALUN_WGRAD_V(1, 5)
       else if (nit == 6) SALUN_WGRAD_V(1, 6)
       else if (nit == 8) SALUN_WGRAD_V(1, 8)

@@ -94,3 +94,35 @@ def test_unsupported_shapes_are_refused():
     assert not ops.conv2d_bf16_supported(4, 320, 3, 1, 1)      # the RGB-like stem stays on the fp32 kernels
     assert not ops.conv2d_bf16_supported(320, 4, 3, 1, 1)
     assert not ops.conv2d_bf16_supported(64, 64, 5, 1, 2)
+
+
+@pytest.mark.parametrize("M_shape,C,K,bias", [((8, 4096), 320, 320, False), ((8, 77), 768, 320, False),
+                                              ((2, 1024), 640, 5120, True), ((3, 50), 64, 96, True)])
+def test_linear_on_the_1x1_kernels_matches_fp32_linear(M_shape, C, K, bias):
+    """SalunLinearBF16 (a Linear layer = 1x1 convolution over the tokens, K11 kernels) vs F.linear in fp32 on the same
+    bf16-rounded inputs: forward, dx, dW, db, and the residual in the epilogue.  Tolerance 2e-2 of each tensor's scale
+    (bf16 output / input-gradient rounding; dW / db are fp32 sums of bf16 products: 1e-2)."""
+    from unlearn_saliency_amd.conv_bf16 import SalunLinearBF16
+    g = torch.Generator(device="cuda").manual_seed(sum(M_shape) + C)
+    lin = torch.nn.Linear(C, K, bias=bias).cuda()
+    lin.__class__ = SalunLinearBF16
+    x = torch.randn(*M_shape, C, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    res = torch.randn(*M_shape, K, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    dy = torch.randn(*M_shape, K, device="cuda", generator=g).to(torch.bfloat16)
+    y = lin(x, addend=res)
+    assert y.dtype == torch.bfloat16 and y.shape == (*M_shape, K)
+    y.backward(dy)
+    wq = lin.weight.detach().to(torch.bfloat16).float()
+    xf = x.detach().float().requires_grad_(True)
+    wf = wq.clone().requires_grad_(True)
+    bf = lin.bias.detach().clone().requires_grad_(True) if bias else None
+    yr = torch.nn.functional.linear(xf, wf, bf) + res.detach().float()
+    yr.backward(dy.float())
+    rel = lambda a, b: float((a.float() - b).abs().max() / b.abs().max().clamp_min(1e-6))
+    errs = {"y": rel(y, yr), "dx": rel(x.grad, xf.grad), "dw": rel(lin.weight.grad, wf.grad),
+            "dres": rel(res.grad, dy.float())}
+    if bias:
+        errs["db"] = rel(lin.bias.grad, bf.grad)
+    print(M_shape, C, K, {k: f"{v:.1e}" for k, v in errs.items()})
+    assert errs["y"] <= 2e-2 and errs["dx"] <= 2e-2 and errs["dw"] <= 1e-2 and errs["dres"] == 0.0
+    assert not bias or errs["db"] <= 1e-2

@@ -119,3 +119,22 @@ def test_pack_cache_sees_in_place_writes_on_the_flat_arena():
         assert len(calls) == 3
     finally:
         ops.conv2d_bf16_pack = real
+
+
+def test_linear_layers_of_the_transformer_blocks_are_reclassed():
+    """Round 3: the transformer blocks' Linear layers go to the K11 1x1 kernels in the bf16 configuration — 10 per block
+    (attn1 / attn2: to_q, to_k, to_v, to_out; the GEGLU and output projections) x 16 blocks; the time-embedding Linears
+    stay; names / state_dict untouched; on the host (fp32, no autocast) the module is plain F.linear."""
+    from unlearn_saliency_amd.SD.unet import UNetModel, V1_UNET_CONFIG
+    from unlearn_saliency_amd.conv_bf16 import SalunLinearBF16, use_salun_linears_bf16
+    with torch.device("meta"):
+        m = UNetModel(**V1_UNET_CONFIG)
+    names = [n for n, _ in m.named_parameters()]
+    assert use_salun_linears_bf16(m) == 160
+    assert [n for n, _ in m.named_parameters()] == names
+    assert not isinstance(m.time_embed[0], SalunLinearBF16)
+    lin = torch.nn.Linear(64, 96)
+    ref = lin(torch.ones(3, 5, 64))
+    lin.__class__ = SalunLinearBF16
+    assert torch.equal(lin(torch.ones(3, 5, 64)), ref)
+    assert torch.equal(lin(torch.ones(3, 5, 64), addend=torch.ones(3, 5, 96)), ref + 1)

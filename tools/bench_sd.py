@@ -34,6 +34,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--library_conv", action="store_true")
+    ap.add_argument("--own_linear", action="store_true",
+                    help="A/B: run the transformer blocks' Linear layers on the K11 1x1 kernels instead of the library GEMM")
     a = ap.parse_args(argv)
     from unlearn_saliency_amd import dist as sdist
     from unlearn_saliency_amd import ops
@@ -53,13 +55,15 @@ def main(argv=None):
     arena = TS._unet_arena(model)
     assert arena.n == NS, arena.n
     n_filled = model.fill_zero_initialised()  # zero_module layers / biases -> N(0, 0.02): gradients flow everywhere
-    n_salun = 0
+    n_salun = n_linear = 0
     from unlearn_saliency_amd import conv as sconv
     if not a.library_conv and not a.bf16:
         n_salun = sconv.use_salun_convs(model)
     elif not a.library_conv:
-        from unlearn_saliency_amd.conv_bf16 import use_salun_convs_bf16
+        from unlearn_saliency_amd.conv_bf16 import use_salun_convs_bf16, use_salun_linears_bf16
         n_salun = use_salun_convs_bf16(model)
+        if a.own_linear:  # A/B: the transformer blocks' Linear layers on the K11 1x1 kernels (slower: see ldm_lite.py)
+            n_linear = use_salun_linears_bf16(model)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0
     B = a.batch
@@ -144,7 +148,7 @@ def main(argv=None):
                                "(BASELINE.json configs[4])",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "dtype": "bf16 autocast (fp32 master weights / Adam)" if a.bf16 else "f32", "data": "synthetic",
-        "params": NS, "zero_initialised_elements_filled": n_filled, "salun_mfma_convs": n_salun, "library_conv_calls": sconv.library_conv_calls(), "init_sec": t_init,
+        "params": NS, "zero_initialised_elements_filled": n_filled, "salun_mfma_convs": n_salun, "salun_mfma_linears": n_linear, "library_conv_calls": sconv.library_conv_calls(), "init_sec": t_init,
         "mask_gen": {"batches": a.mask_batches, "saliency_sec": t_mask, "topk_ms_at_NS": topk_ms,
                      "topk_GBps_algorithmic": 5.0 * NS / (topk_ms * 1e-3) / 1e9},
         "roofline": {"kernel": "salun_masked_adam_step @ N_S" + ("" if not sdist.collectives_on() else

@@ -52,7 +52,13 @@ class LatentDiffusionLite(nn.Module):
         """Put the U-Net's convolutions on this package's matrix-core kernels: bf16 NHWC (conv_bf16.py, K11) in the
         bf16 configuration, fp32 NCHW (conv.py, K8) otherwise.  Returns the number of modules switched."""
         if self.bf16:
-            from ..conv_bf16 import use_salun_convs_bf16
+            from ..conv_bf16 import use_salun_convs_bf16, use_salun_linears_bf16
+            # The transformer blocks' Linear layers CAN run on the K11 1x1 kernels (conv_bf16.SalunLinearBF16: cached
+            # packed weights, fp32 gradient accumulation in the kernel, no casts / AccumulateGrad launches), but the
+            # library GEMM is 1.5-2.3x faster in the forward at these shapes (620-670 vs 265-450 TFLOP/s,
+            # profiles/r03_linearbench_bf16.txt) and the whole step loses 7 % (4.38 vs 4.71 steps/s) — opt-in only.
+            if getattr(self, "mfma_linears", False):
+                self.n_mfma_linears = use_salun_linears_bf16(self.model.diffusion_model)
             return use_salun_convs_bf16(self.model.diffusion_model)
         from ..conv import use_salun_convs
         return use_salun_convs(self.model.diffusion_model)

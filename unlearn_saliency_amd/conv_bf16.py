@@ -97,6 +97,105 @@ class SalunConv2dBF16(nn.Conv2d):
         return _ConvBF16Fn.apply(x, self.weight, self.bias, self, nbias, addend)
 
 
+# ----------------------------------------------------------------------------------------------- Linear layers
+# A Linear layer on a token tensor [.., M tokens, C] IS a 1x1 convolution over an NHWC image whose pixels are the
+# tokens — the layout the K11 kernels already read — so the transformer blocks' projections (to_q / to_k / to_v /
+# to_out, the GEGLU and output projections of the feed-forward; SD/ldm/modules/attention.py:37-75,168-247) run on
+# conv_bf16_igemm / conv_bf16_wgrad instead of the library GEMM: the bf16 weight image is packed once per optimizer
+# step (not cast on every forward, recompute and backward), the bias (and, where the caller passes one, the residual)
+# rides in the epilogue, and dW / db are added in fp32 straight into the flat gradient (no bf16 gradient, no cast, no
+# AccumulateGrad launch).
+def _tokens_nhwc(t: torch.Tensor, C: int) -> torch.Tensor:
+    """[..., C] -> contiguous bf16 [1, H, W, C] with H * W = number of tokens (W = 8 when it divides: the backward-weight
+    kernel walks 8 x 8 pixel blocks)."""
+    t = t.to(torch.bfloat16).contiguous()
+    M = t.numel() // C
+    return t.view(1, M // 8, 8, C) if M % 8 == 0 else t.view(1, M, 1, C)
+
+
+class _LinearBF16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, mod, addend):
+        K, C = w.shape
+        xn = _tokens_nhwc(x, C)
+        an = _tokens_nhwc(addend, K) if addend is not None else None
+        y = ops.conv2d_bf16_forward(xn, mod.packed_weight(), 1, 1, 0, bias=bias, nbias=None, addend=an)
+        ctx.save_for_backward(xn, w)
+        ctx.mod, ctx.has_bias, ctx.x_shape, ctx.x_dtype = mod, bias is not None, tuple(x.shape), x.dtype
+        ctx.addend_dtype = addend.dtype if addend is not None else None
+        return y.view(*x.shape[:-1], K)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, w = ctx.saved_tensors
+        mod = ctx.mod
+        K, C = w.shape
+        dyn = _tokens_nhwc(dy, K)
+        dx = dw = db = dadd = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dst = gradsink.sink(w)
+            bdst = gradsink.sink(mod.bias) if (ctx.has_bias and dst is not None) else None
+            if ctx.has_bias and bdst is None:
+                bdst = torch.zeros(K, dtype=torch.float32, device=w.device)
+                db = bdst
+            got = ops.conv2d_bf16_backward_weight(xn, dyn, (K, C, 1, 1), 1, 0,
+                                                  out=dst.view(K, C, 1, 1) if dst is not None else None,
+                                                  accumulate=True, bias_out=bdst)
+            if dst is None:
+                dw = got.view(K, C)
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_bf16_backward_data(dyn, mod.packed_weight(), tuple(xn.shape), 1, 1, 0).view(ctx.x_shape)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        if ctx.addend_dtype is not None and ctx.needs_input_grad[4]:
+            dadd = dy if dy.dtype == ctx.addend_dtype else dy.to(ctx.addend_dtype)
+        return dx, dw, db, None, dadd
+
+
+class SalunLinearBF16(nn.Linear):
+    """Same parameters / state_dict as nn.Linear.  Device inputs in the bf16 configuration (a bf16 tensor, or any
+    tensor under bf16 autocast) go through the bf16 MFMA kernels; anything else is the plain fp32 F.linear."""
+
+    _pack = None
+    _pack_key = None
+
+    def packed_weight(self) -> torch.Tensor:
+        w = self.weight
+        flat = getattr(w, "_salun_flat", None)
+        key = (ops.PARAM_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
+        if self._pack is None or self._pack_key != key or self._pack.device != w.device:
+            K, C = w.shape
+            self._pack = ops.conv2d_bf16_pack(w.detach().view(K, C, 1, 1),
+                                              self._pack if self._pack is not None and self._pack.device == w.device else None)
+            self._pack_key = key
+        return self._pack
+
+    def forward(self, x, addend=None):
+        """`addend` (a tensor of the output's shape, e.g. the residual branch) is added in the kernel's epilogue."""
+        bf16_mode = x.is_cuda and (x.dtype == torch.bfloat16 or
+                                   (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16))
+        if bf16_mode:
+            return _LinearBF16Fn.apply(x, self.weight, self.bias, self, addend)
+        y = torch.nn.functional.linear(x, self.weight, self.bias)
+        return y if addend is None else y + addend
+
+
+def use_salun_linears_bf16(model: nn.Module) -> int:
+    """Re-class the nn.Linear layers of the transformer blocks (feature counts that are multiples of 32) in place;
+    returns how many were switched.  The two tiny time-embedding Linears (M = batch rows) stay on the library."""
+    from .SD.unet import BasicTransformerBlock
+    n = 0
+    for blk in model.modules():
+        if not isinstance(blk, BasicTransformerBlock):
+            continue
+        for mod in blk.modules():
+            if type(mod) is nn.Linear and mod.in_features % 32 == 0 and mod.out_features % 32 == 0 and \
+                    ops.conv2d_bf16_supported(mod.in_features, mod.out_features, 1, 1, 0):
+                mod.__class__ = SalunLinearBF16
+                n += 1
+    return n
+
+
 class _Fp32Island(SalunConv2d):
     """The two 4-channel convolutions of the U-Net (latent head / tail) inside a bf16 model: fp32 MFMA kernels on an
     fp32 NCHW copy of the input; the result keeps fp32 (the head feeds GroupNorm, the tail is the model output)."""

@@ -173,7 +173,7 @@ class SalunLinearBF16(nn.Linear):
     def forward(self, x, addend=None):
         """`addend` (a tensor of the output's shape, e.g. the residual branch) is added in the kernel's epilogue."""
         bf16_mode = x.is_cuda and (x.dtype == torch.bfloat16 or
-                                   (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16))
+                                   (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16))
         if bf16_mode:
             return _LinearBF16Fn.apply(x, self.weight, self.bias, self, addend)
         y = torch.nn.functional.linear(x, self.weight, self.bias)

@@ -2190,8 +2190,8 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
   float *part = static_cast<float *>(ws);
   // vectorised staging (conv_wgrad_v) where the geometry allows it: 3x3, pad 1, full channel tiles, whole image rows
   bool vec_done = false;
-  if (R == 3 && pad == 1 && C % 64 == 0 && W % 4 == 0 && Q * stride == W && P * stride == H &&
-      (size_t)g.NI * C * H * W < (1u << 30)) {
+  if (R == 3 && pad == 1 && C % 64 == 0 && W % 4 == 0 && Q * stride == W && P * stride == H && salun_aligned16(x) &&
+      salun_aligned16(dy) && (size_t)g.NI * C * H * W < (1u << 30)) {
     const int F4C = g.NI * g.IH_t * (W / 4);
     const int nit = (F4C % 4 == 0) ? F4C / 4 : 0;
 #define SALUN_WGRAD_V(S_, NIT_)                                                                                \

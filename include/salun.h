@@ -228,6 +228,14 @@ int salun_fim_square_accumulate(float *F /*dev*/, float *tmp /*dev*/, double n_d
 int salun_conv2d_forward(const float *x /*dev*/, const float *w /*dev*/, const float *bias /*dev or NULL*/,
                          float *y /*dev*/, int N, int C, int H, int W, int K, int R, int stride, int pad,
                          int P, int Q, salun_stream_t stream);
+/* Forward with the epilogue of a diffusion ResnetBlock (DDPM/models/diffusion.py:113-127 of the reference:
+ * `h = conv1(..); h = h + temb_proj(..)[:, :, None, None]` and `return x + h`) folded in:
+ *   y = conv2d(x, w) + bias[k] + nbias[n][k] + addend[n][k][p][q]      (each term optional, added in that order —
+ * the order the reference's separate adds produce).  addend must not alias y. */
+int salun_conv2d_forward_fused(const float *x /*dev*/, const float *w /*dev*/, const float *bias /*dev or NULL*/,
+                               const float *nbias /*dev [N,K] or NULL*/, const float *addend /*dev [N,K,P,Q] or NULL*/,
+                               float *y /*dev*/, int N, int C, int H, int W, int K, int R, int stride, int pad,
+                               int P, int Q, salun_stream_t stream);
 int salun_conv2d_backward_data(const float *dy /*dev*/, const float *w /*dev*/, float *dx /*dev*/, int N, int C,
                                int H, int W, int K, int R, int stride, int pad, int P, int Q,
                                salun_stream_t stream);
@@ -386,6 +394,19 @@ int salun_gn_backward(const float *dz /*dev*/, const float *x /*dev*/, const flo
                       float *grad_gamma_acc /*dev or NULL: += dgamma*/, float *grad_beta_acc /*dev or NULL*/,
                       int N, int C, int HW, int G, int silu, void *ws /*dev*/, size_t ws_bytes,
                       salun_stream_t stream);
+
+/* Backward with the neighbours of a diffusion ResnetBlock folded in: dx (+= addend: the skip branch's gradient,
+ * [N,C,HW] or NULL, must not alias dx); nk_sum (N*C floats or NULL) = sum over hw of the dx written, per (image,
+ * channel) — the gradient of the per-image channel bias added by the convolution that produced x (the embedding
+ * projection); csum / csum_acc (C floats or NULL; need nk_sum) = / += sum over n of nk_sum — that convolution's
+ * bias gradient.  All reductions in fixed order. */
+int salun_gn_backward_fused(const float *dz /*dev*/, const float *x /*dev*/, const float *gamma /*dev*/,
+                            const float *beta /*dev*/, const float *save_mean /*dev*/, const float *save_rstd /*dev*/,
+                            const float *addend /*dev or NULL*/, float *dx /*dev*/, float *dgamma /*dev*/,
+                            float *dbeta /*dev*/, float *grad_gamma_acc /*dev or NULL*/,
+                            float *grad_beta_acc /*dev or NULL*/, float *nk_sum /*dev or NULL*/,
+                            float *csum /*dev or NULL*/, float *csum_acc /*dev or NULL*/, int N, int C, int HW, int G,
+                            int silu, void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 
 /* ------------------------------------------------------------------ K9 --
  * Proximal (soft-threshold) step of RL_proximal — Classification/unlearn/RL_pro.py:52-60:

@@ -96,6 +96,7 @@ class ResnetBlock(nn.Module):
         self.norm2 = group_norm(out_channels)
         self.dropout = nn.Dropout(dropout)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        self.fused_node = False  # set by conv.use_salun_convs(model): the whole block as one autograd node
         if in_channels != out_channels:
             if conv_shortcut:
                 self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
@@ -104,6 +105,11 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x, emb_act):
         """emb_act = swish([temb ‖ cemb]) — identical for every block, computed once per forward."""
+        if self.fused_node:
+            from ...resblock import fused_diffusion_resnet_block
+            out = fused_diffusion_resnet_block(self, x, emb_act)
+            if out is not None:
+                return out
         h = self.conv1(fused_gn_act(x, self.norm1, silu=True))  # swish(norm1(x)) as one kernel
         h = h + self.temb_cemb_proj(emb_act)[:, :, None, None]
         h = self.conv2(self.dropout(fused_gn_act(h, self.norm2, silu=True)))

@@ -57,6 +57,7 @@ SIGNATURES = {
                                  c_void_p, c_size_t, c_void_p]),
     "salun_fim_square_accumulate": (c_int, [c_void_p, c_void_p, c_double, c_int64, c_void_p]),
     "salun_conv2d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "salun_conv2d_forward_fused": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),
     "salun_conv2d_backward_data": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "salun_channel_sum_workspace_bytes": (c_size_t, [c_int] * 2),
     "salun_channel_sum": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
@@ -88,6 +89,7 @@ SIGNATURES = {
     "salun_gn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "salun_gn_forward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_double, c_int, c_void_p]),
     "salun_gn_backward": (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "salun_gn_backward_fused": (c_int, [c_void_p] * 15 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "salun_param_diff": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "salun_soft_threshold_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "salun_ewc_workspace_bytes": (c_size_t, [c_int64]),

@@ -10,6 +10,8 @@ benchmarks as `library_conv_calls`), and `strict(True)` turns the fallback into 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -21,6 +23,10 @@ from . import gradsink, ops, resblock
 # calls that went to the library (MIOpen) instead of the MFMA kernels, by reason
 LIBRARY_CONV_CALLS = {"shape": 0, "dtype_or_autocast": 0, "backward": 0}
 _STRICT = [False]
+
+
+# SALUN_BLOCK_NODES=0: keep the diffusion ResnetBlocks as separate autograd nodes (A/B switch for the benchmarks)
+_BLOCK_NODES = [os.environ.get("SALUN_BLOCK_NODES", "1") != "0"]
 
 
 def strict(on: bool = True) -> None:
@@ -142,6 +148,9 @@ def use_salun_convs(model: nn.Module) -> int:
             mod.use_mfma = True
             n += 1
             continue
+    for mod in model.modules():
+        if hasattr(mod, "fused_node") and hasattr(mod, "temb_cemb_proj"):  # DDPM ResnetBlock: one autograd node
+            mod.fused_node = _BLOCK_NODES[0]
     owners = {id(m.conv) for m in model.modules() if getattr(m, "use_mfma", False) and hasattr(m, "conv")}
     for mod in model.modules():
         if type(mod) is nn.Conv2d and _eligible(mod) and id(mod) not in owners:

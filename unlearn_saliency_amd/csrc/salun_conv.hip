@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
                                                   const float *__restrict__ bias, float *__restrict__ y, int N,
                                                   int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
                                                   int TP, int IH_t, int IW_t, int logQ, int wC /*w dim1 (C of OIHW)*/,
-                                                  int wK /*w dim0*/) {
+                                                  int wK /*w dim0*/, const float *__restrict__ nbias /*[N][yC] or null*/,
+                                                  const float *__restrict__ addend /*forward: [N][yC][yH][yW] or null*/) {
   constexpr int RS = R * R;
   constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
   constexpr int WROW = CC * RS + 1;    // LDS weight row (odd => conflict-free across 32 rows)
@@ -338,7 +339,16 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
           if (k < yC) {
             float o = acc[pt][t][v];
             const size_t oi = (((size_t)n_out * yC + k) * P + p_out) * Q + q_l[pt];
-            if (bias) o += DGRAD ? bias[oi] : bias[k];  // backward-data: `bias` is a full-size addend (may alias y)
+            if (DGRAD) {
+              if (bias) o += bias[oi];  // backward-data: `bias` is a full-size addend (may alias y)
+            } else {
+              // forward: per-channel bias, then the per-image channel bias (the time/class embedding projection of a
+              // diffusion ResnetBlock), then a full-size addend (the block's skip branch) — the order the reference's
+              // separate adds produce (DDPM/models/diffusion.py:113-127)
+              if (bias) o += bias[k];
+              if (nbias) o += nbias[(size_t)n_out * yC + k];
+              if (addend) o += addend[oi];
+            }
             y[oi] = o;
           }
         }
@@ -1754,7 +1764,8 @@ inline TileGeom make_geom(int N, int P, int Q, int pixt, int cs, int R) {
 
 template <int R, int STRIDE, bool DGRAD>
 int launch_igemm(const float *x, const float *w, const float *bias, float *y, int N, int xC, int xH, int xW, int yC,
-                 int yH, int yW, int pad, int wC, int wK, hipStream_t st) {
+                 int yH, int yW, int pad, int wC, int wK, hipStream_t st, const float *nbias = nullptr,
+                 const float *addend = nullptr) {
   // tile shape: prefer 128 pixels x up to 128 channels; shrink when that leaves the chip under-filled
   const int cs = DGRAD ? 1 : STRIDE;
   int pixt = 128;
@@ -1779,11 +1790,13 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
     if (fast) {                                                                                                 \
       allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>, ldsb);                                       \
       hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>), grid, dim3(256), ldsb, st, x, w,  \
-                         bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK);  \
+                         bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK,   \
+                         nbias, addend);                                                                        \
     } else {                                                                                                    \
       allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, false>, ldsb);                                      \
       hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, false>), grid, dim3(256), ldsb, st, x, w, \
-                         bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK);  \
+                         bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK,   \
+                         nbias, addend);                                                                        \
     }                                                                                                           \
   }
   if (pixt == 128) {
@@ -1801,7 +1814,8 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
         dim3 grid2(g256.ntiles, (yC + 63) / 64);
         allow_lds(conv_igemm<R, STRIDE, 2, 4, 1, DGRAD, true, 2>, ldsb2);
         hipLaunchKernelGGL((conv_igemm<R, STRIDE, 2, 4, 1, DGRAD, true, 2>), grid2, dim3(256), ldsb2, st, x, w, bias, y,
-                           N, xC, xH, xW, yC, yH, yW, pad, g256.NI, g256.TP, g256.IH_t, g256.IW_t, g256.logQ, wC, wK);
+                           N, xC, xH, xW, yC, yH, yW, pad, g256.NI, g256.TP, g256.IH_t, g256.IW_t, g256.logQ, wC, wK, nbias,
+                           addend);
       } else SALUN_IGEMM(2, 4, 1)
     }
     else SALUN_IGEMM(1, 4, 1)
@@ -2002,16 +2016,26 @@ inline int wgrad_nsplit(int K, int C, int nchunks) {
 // y[N,K,P,Q] = conv2d(x[N,C,H,W], w[K,C,R,R], stride, pad_lo) (+ bias[K]); P,Q given by the caller
 // (so asymmetric high-side padding is expressed through P,Q).  Returns SALUN_EINVAL for shapes outside the
 // tiling's domain (Q not a power of two, ...): the caller then uses the library convolution.
+SALUN_EXPORT int salun_conv2d_forward_fused(const float *x, const float *w, const float *bias, const float *nbias,
+                                            const float *addend, float *y, int N, int C, int H, int W, int K, int R,
+                                            int stride, int pad, int P, int Q, salun_stream_t stream) {
+  if (!x || !w || !y || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1 || addend == y) return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  if (R == 3 && stride == 1)
+    return launch_igemm<3, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend);
+  if (R == 3 && stride == 2)
+    return launch_igemm<3, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend);
+  if (R == 1 && stride == 1)
+    return launch_igemm<1, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend);
+  if (R == 1 && stride == 2)
+    return launch_igemm<1, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend);
+  return SALUN_EINVAL;
+}
+
 SALUN_EXPORT int salun_conv2d_forward(const float *x, const float *w, const float *bias, float *y, int N, int C,
                                       int H, int W, int K, int R, int stride, int pad, int P, int Q,
                                       salun_stream_t stream) {
-  if (!x || !w || !y || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
-  hipStream_t st = salun_hip_stream(stream);
-  if (R == 3 && stride == 1) return launch_igemm<3, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
-  if (R == 3 && stride == 2) return launch_igemm<3, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
-  if (R == 1 && stride == 1) return launch_igemm<1, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
-  if (R == 1 && stride == 2) return launch_igemm<1, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st);
-  return SALUN_EINVAL;
+  return salun_conv2d_forward_fused(x, w, bias, nullptr, nullptr, y, N, C, H, W, K, R, stride, pad, P, Q, stream);
 }
 
 // dx[N,C,H,W] = conv2d_backward_data(dy[N,K,P,Q], w[K,C,R,R]) (+ addend[N,C,H,W]; addend == dx accumulates in place)

@@ -356,10 +356,14 @@ __global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, flo
   double d1 = 0.0, d2 = 0.0;
   if (CACHED) {
 #pragma unroll
+    for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {  // all loads in flight before the first use
+      const int e = threadIdx.x + i * 256;
+      if (e < nvec) v[i] = xv[e];
+    }
+#pragma unroll
     for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {
       const int e = threadIdx.x + i * 256;
       if (e < nvec) {
-        v[i] = xv[e];
         s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
       }
@@ -415,12 +419,17 @@ __global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, flo
 
 // Backward.  seg: aligned run of r = min(HW/4, 64) lanes inside one channel; segment sums go to LDS, channel sums
 // are folded from them by one lane per channel, group sums from the channel sums — all in fixed order.
-template <bool SILU, int ITEMS>
+// EXTRA (the diffusion ResnetBlock node, resblock.py): `addend` (same shape as dx, or null) is added to dx before the
+// store — the skip branch's gradient, instead of a separate add pass — and `nk_sum` (N*C floats, or null) receives
+// sum_hw of the dx written per (image, channel): the gradient of the per-image channel bias the producing convolution
+// added (the time/class embedding projection) and, folded over n by k_gn_bwd_final, of that convolution's bias.
+template <bool SILU, int ITEMS, bool EXTRA>
 __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, const float *__restrict__ x,
                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                 float *__restrict__ dx, float *__restrict__ part_dgamma,
-                                                float *__restrict__ part_dbeta, int C, int HW, int G) {
+                                                float *__restrict__ part_dbeta, int C, int HW, int G,
+                                                const float *__restrict__ addend, float *__restrict__ nk_sum) {
   constexpr bool CACHED = ITEMS > 0;
   __shared__ float seg_g[GN_MAX_SEG], seg_b[GN_MAX_SEG];
   __shared__ float grp[2];
@@ -434,11 +443,10 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
   const int r = hw4 < 64 ? hw4 : 64;          // lanes per segment (power of two)
   const int segs_per_ch = hw4 / r;            // >= 1
   float4 xc[CACHED ? ITEMS : 1], dc[CACHED ? ITEMS : 1];
+  float gac[CACHED ? ITEMS : 1], bec[CACHED ? ITEMS : 1];  // gamma / beta of each cached float4's channel
 
   // dy (gradient w.r.t. the normalised, affine output) of one float4, from x and dz
-  auto dy_of = [&](int e, float4 xt, float4 gt, float4 &xh) {
-    const int c = g * cpg + e / hw4;
-    const float ga = gamma[c], be = beta[c];
+  auto dy_of = [&](float ga, float be, float4 xt, float4 gt, float4 &xh) {
     xh.x = (xt.x - mu) * rs; xh.y = (xt.y - mu) * rs; xh.z = (xt.z - mu) * rs; xh.w = (xt.w - mu) * rs;
     if (SILU) {
       const float y0 = xh.x * ga + be, y1 = xh.y * ga + be, y2 = xh.z * ga + be, y3 = xh.w * ga + be;
@@ -462,16 +470,26 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
   };
   const int nround = (nvec + 255) / 256;  // every lane walks the same number of rounds (shuffles need all lanes)
   if (CACHED) {
+    // every load of the group is issued before the first use (2 * ITEMS float4 in flight per lane): with the loads
+    // inside the reduction rounds each round waited for its own two loads and the kernel ran at a third of HBM speed
+#pragma unroll
+    for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < nvec) {
+        xc[i] = xv[e];
+        dc[i] = gv[e];
+        const int c = g * cpg + e / hw4;
+        gac[i] = gamma[c];
+        bec[i] = beta[c];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {
       if (i < nround) {
         const int e = threadIdx.x + i * 256;
         const bool valid = e < nvec;
         float4 xh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) {
-          xc[i] = xv[e];
-          dc[i] = dy_of(e, xc[i], gv[e], xh);
-        }
+        if (valid) dc[i] = dy_of(gac[i], bec[i], xc[i], dc[i], xh);
         seg_accumulate(valid ? e : 0, valid ? dc[i] : xh, xh, valid);
       }
     }
@@ -480,7 +498,10 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
       const int e = threadIdx.x + i * 256;
       const bool valid = e < nvec;
       float4 xh = make_float4(0.f, 0.f, 0.f, 0.f), d = xh;
-      if (valid) d = dy_of(e, xv[e], gv[e], xh);
+      if (valid) {
+        const int c = g * cpg + e / hw4;
+        d = dy_of(gamma[c], beta[c], xv[e], gv[e], xh);
+      }
       seg_accumulate(valid ? e : 0, d, xh, valid);
     }
   }
@@ -512,26 +533,62 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
   __syncthreads();
   const float ma = grp[0], mb = grp[1];
   float4 *ov = reinterpret_cast<float4 *>(dx + base);
-  auto emit = [&](int e, float4 xt, float4 dyv) {
-    const float ga = gamma[g * cpg + e / hw4];
+  const float4 *av = reinterpret_cast<const float4 *>(EXTRA && addend ? addend + base : nullptr);
+  auto emit = [&](int e, float ga, float4 xt, float4 dyv) {
     float4 o;
     o.x = rs * (dyv.x * ga - ma - ((xt.x - mu) * rs) * mb);
     o.y = rs * (dyv.y * ga - ma - ((xt.y - mu) * rs) * mb);
     o.z = rs * (dyv.z * ga - ma - ((xt.z - mu) * rs) * mb);
     o.w = rs * (dyv.w * ga - ma - ((xt.w - mu) * rs) * mb);
+    if (EXTRA && av) {
+      const float4 ad = av[e];
+      o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+    }
     ov[e] = o;
+    return o;
+  };
+  const bool want_nk = EXTRA && nk_sum != nullptr;  // uniform
+  auto nk_accumulate = [&](int e, float4 o, bool valid) {  // segment sums of the written dx -> seg_g (free again here)
+    float sv = valid ? (o.x + o.y) + (o.z + o.w) : 0.f;
+    sv = seg_sum(sv, r);
+    if (valid && (threadIdx.x & (r - 1)) == 0) seg_g[e / r] = sv;
   };
   if (CACHED) {
 #pragma unroll
     for (int i = 0; i < (CACHED ? ITEMS : 1); ++i) {
       const int e = threadIdx.x + i * 256;
-      if (e < nvec) emit(e, xc[i], dc[i]);
+      const bool valid = e < nvec;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) o = emit(e, gac[i], xc[i], dc[i]);
+      if (EXTRA) {
+        if (want_nk && i < nround) nk_accumulate(valid ? e : 0, o, valid);
+      }
     }
   } else {
-    for (int e = threadIdx.x; e < nvec; e += 256) {
-      float4 xh;
-      const float4 xt = xv[e];
-      emit(e, xt, dy_of(e, xt, gv[e], xh));
+    for (int i = 0; i < nround; ++i) {
+      const int e = threadIdx.x + i * 256;
+      const bool valid = e < nvec;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        float4 xh;
+        const float4 xt = xv[e];
+        const int c = g * cpg + e / hw4;
+        const float ga = gamma[c];
+        o = emit(e, ga, xt, dy_of(ga, beta[c], xt, gv[e], xh));
+      }
+      if (EXTRA) {
+        if (want_nk) nk_accumulate(valid ? e : 0, o, valid);
+      }
+    }
+  }
+  if (EXTRA) {
+    if (want_nk) {
+      __syncthreads();
+      if ((int)threadIdx.x < cpg) {
+        float t = 0.f;
+        for (int sgi = 0; sgi < segs_per_ch; ++sgi) t += seg_g[threadIdx.x * segs_per_ch + sgi];
+        nk_sum[(size_t)n * C + g * cpg + threadIdx.x] = t;
+      }
     }
   }
 }
@@ -541,24 +598,30 @@ __global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dz, co
 __global__ __launch_bounds__(256) void k_gn_bwd_final(const float *__restrict__ part_dgamma,
                                                       const float *__restrict__ part_dbeta, int N, int C,
                                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                      float *__restrict__ gacc, float *__restrict__ bacc) {
-  __shared__ double s_g[8][33], s_b[8][33];
+                                                      float *__restrict__ gacc, float *__restrict__ bacc,
+                                                      const float *__restrict__ part_nk /*[N][C] or null*/,
+                                                      float *__restrict__ csum /*[C] or null: = sum_n part_nk*/,
+                                                      float *__restrict__ csum_acc /*[C] or null: += the same*/) {
+  __shared__ double s_g[8][33], s_b[8][33], s_k[8][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
-  double sg = 0.0, sb = 0.0;
+  double sg = 0.0, sb = 0.0, sk = 0.0;
   if (c < C)
     for (int n = ry; n < N; n += 8) {
       sg += (double)part_dgamma[(size_t)n * C + c];
       sb += (double)part_dbeta[(size_t)n * C + c];
+      if (part_nk) sk += (double)part_nk[(size_t)n * C + c];
     }
-  s_g[ry][cx] = sg; s_b[ry][cx] = sb;
+  s_g[ry][cx] = sg; s_b[ry][cx] = sb; s_k[ry][cx] = sk;
   __syncthreads();
   if (ry != 0 || c >= C) return;
-  for (int q = 1; q < 8; ++q) { sg += s_g[q][cx]; sb += s_b[q][cx]; }
+  for (int q = 1; q < 8; ++q) { sg += s_g[q][cx]; sb += s_b[q][cx]; sk += s_k[q][cx]; }
   dgamma[c] = (float)sg;
   dbeta[c] = (float)sb;
   if (gacc) gacc[c] += (float)sg;
   if (bacc) bacc[c] += (float)sb;
+  if (part_nk && csum) csum[c] = (float)sk;
+  if (part_nk && csum_acc) csum_acc[c] += (float)sk;
 }
 
 // float4 per lane kept in registers: the smallest of 1, 2, 4, 8, 16 covering the group; 0 = too large, re-read mode
@@ -610,34 +673,54 @@ SALUN_EXPORT int salun_gn_forward(const float *x, float *y, const float *gamma, 
 }
 
 // dx, dgamma, dbeta of  z = [silu](GroupNorm(x))  given dz; y and sigma(y) are recomputed from x.
-SALUN_EXPORT int salun_gn_backward(const float *dz, const float *x, const float *gamma, const float *beta,
-                                   const float *save_mean, const float *save_rstd, float *dx, float *dgamma,
-                                   float *dbeta, float *grad_gamma_acc, float *grad_beta_acc, int N, int C, int HW,
-                                   int G, int silu, void *ws, size_t ws_bytes, salun_stream_t stream) {
+// Fused form: dx += addend (optional, [N,C,HW]); nk_sum (optional, N*C floats) = sum_hw dx per (image, channel);
+// csum / csum_acc (optional, C floats, need nk_sum) = / += sum_n nk_sum.
+SALUN_EXPORT int salun_gn_backward_fused(const float *dz, const float *x, const float *gamma, const float *beta,
+                                         const float *save_mean, const float *save_rstd, const float *addend,
+                                         float *dx, float *dgamma, float *dbeta, float *grad_gamma_acc,
+                                         float *grad_beta_acc, float *nk_sum, float *csum, float *csum_acc, int N,
+                                         int C, int HW, int G, int silu, void *ws, size_t ws_bytes,
+                                         salun_stream_t stream) {
   if (!dz || !x || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !gn_shape_ok(N, C, HW, G))
     return SALUN_EINVAL;
+  if ((csum || csum_acc) && !nk_sum) return SALUN_EINVAL;
+  if (addend == dx) return SALUN_EINVAL;
   if (!ws || ws_bytes < salun_gn_workspace_bytes(N, C)) return SALUN_ENOSPC;
-  if (!salun_aligned16(dz) || !salun_aligned16(x) || !salun_aligned16(dx)) return SALUN_EINVAL;
+  if (!salun_aligned16(dz) || !salun_aligned16(x) || !salun_aligned16(dx) || (addend && !salun_aligned16(addend)))
+    return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
   float *pg = static_cast<float *>(ws), *pb = pg + (size_t)N * C;
   const int items = gn_items(C, HW, G);
-#define SALUN_GN_BWD(S_, I_) \
-  hipLaunchKernelGGL((k_gn_bwd<S_, I_>), dim3(N * G), dim3(256), 0, st, dz, x, gamma, beta, save_mean, save_rstd, dx, pg, pb, C, HW, G)
-#define SALUN_GN_BWD_I(S_)                    \
-  switch (items) {                            \
-    case 1: SALUN_GN_BWD(S_, 1); break;       \
-    case 2: SALUN_GN_BWD(S_, 2); break;       \
-    case 4: SALUN_GN_BWD(S_, 4); break;       \
-    case 8: SALUN_GN_BWD(S_, 8); break;       \
-    case 16: SALUN_GN_BWD(S_, 16); break;     \
-    default: SALUN_GN_BWD(S_, 0); break;      \
+  const bool extra = addend != nullptr || nk_sum != nullptr;
+#define SALUN_GN_BWD(S_, I_, E_) \
+  hipLaunchKernelGGL((k_gn_bwd<S_, I_, E_>), dim3(N * G), dim3(256), 0, st, dz, x, gamma, beta, save_mean, save_rstd, dx, pg, pb, C, HW, G, addend, nk_sum)
+#define SALUN_GN_BWD_I(S_, E_)                    \
+  switch (items) {                                \
+    case 1: SALUN_GN_BWD(S_, 1, E_); break;       \
+    case 2: SALUN_GN_BWD(S_, 2, E_); break;       \
+    case 4: SALUN_GN_BWD(S_, 4, E_); break;       \
+    case 8: SALUN_GN_BWD(S_, 8, E_); break;       \
+    case 16: SALUN_GN_BWD(S_, 16, E_); break;     \
+    default: SALUN_GN_BWD(S_, 0, E_); break;      \
   }
-  if (silu) { SALUN_GN_BWD_I(true) } else { SALUN_GN_BWD_I(false) }
+  if (silu) {
+    if (extra) { SALUN_GN_BWD_I(true, true) } else { SALUN_GN_BWD_I(true, false) }
+  } else {
+    if (extra) { SALUN_GN_BWD_I(false, true) } else { SALUN_GN_BWD_I(false, false) }
+  }
 #undef SALUN_GN_BWD_I
 #undef SALUN_GN_BWD
   SALUN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gn_bwd_final, dim3((C + 31) / 32), dim3(256), 0, st, pg, pb, N, C, dgamma, dbeta,
-                     grad_gamma_acc, grad_beta_acc);
+                     grad_gamma_acc, grad_beta_acc, nk_sum, csum, csum_acc);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
+}
+
+SALUN_EXPORT int salun_gn_backward(const float *dz, const float *x, const float *gamma, const float *beta,
+                                   const float *save_mean, const float *save_rstd, float *dx, float *dgamma,
+                                   float *dbeta, float *grad_gamma_acc, float *grad_beta_acc, int N, int C, int HW,
+                                   int G, int silu, void *ws, size_t ws_bytes, salun_stream_t stream) {
+  return salun_gn_backward_fused(dz, x, gamma, beta, save_mean, save_rstd, nullptr, dx, dgamma, dbeta, grad_gamma_acc,
+                                 grad_beta_acc, nullptr, nullptr, nullptr, N, C, HW, G, silu, ws, ws_bytes, stream);
 }

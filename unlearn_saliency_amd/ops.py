@@ -255,17 +255,25 @@ def fim_square_accumulate(F: torch.Tensor, tmp: torch.Tensor, n_data: float) -> 
 
 # ----------------------------------------------------------------------------- K8
 def conv2d_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int, pad: int,
-                   P: int, Q: int) -> Optional[torch.Tensor]:
-    """y = conv2d(x, w) (+bias) on the matrix cores; None if the shape is outside the kernel's tiling domain."""
+                   P: int, Q: int, nbias: Optional[torch.Tensor] = None,
+                   addend: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """y = conv2d(x, w) (+ bias[k]) (+ nbias[n, k]) (+ addend[n, k, p, q]) on the matrix cores; None if the shape is
+    outside the kernel's tiling domain."""
     N, C, H, W = x.shape
     K, _, R, _ = w.shape
     y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
-    rc = _lib.lib().salun_conv2d_forward(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"),
-                                         _dev(bias, torch.float32, "bias", True), c_void_p(y.data_ptr()), N, C, H, W,
-                                         K, R, stride, pad, P, Q, _stream())
+    if nbias is not None and tuple(nbias.shape) != (N, K):
+        raise ValueError(f"nbias must be [{N}, {K}], got {tuple(nbias.shape)}")
+    if addend is not None and tuple(addend.shape) != (N, K, P, Q):
+        raise ValueError(f"addend must be {(N, K, P, Q)}, got {tuple(addend.shape)}")
+    rc = _lib.lib().salun_conv2d_forward_fused(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"),
+                                               _dev(bias, torch.float32, "bias", True),
+                                               _dev(nbias, torch.float32, "nbias", True),
+                                               _dev(addend, torch.float32, "addend", True), c_void_p(y.data_ptr()),
+                                               N, C, H, W, K, R, stride, pad, P, Q, _stream())
     if rc == _lib.SALUN_EINVAL:
         return None
-    check(rc, "salun_conv2d_forward")
+    check(rc, "salun_conv2d_forward_fused")
     return y
 
 
@@ -631,22 +639,35 @@ def gn_forward(x, gamma, beta, groups, eps, silu):
     return z, mean, rstd
 
 
-def gn_backward(dz, x, gamma, beta, mean, rstd, groups, silu, gamma_grad_acc=None, beta_grad_acc=None):
-    """-> (dx, dgamma, dbeta)."""
+def gn_backward(dz, x, gamma, beta, mean, rstd, groups, silu, gamma_grad_acc=None, beta_grad_acc=None, addend=None,
+                nk_sum: bool = False, csum: bool = False, csum_acc=None):
+    """-> (dx, dgamma, dbeta), or with `nk_sum` -> (dx, dgamma, dbeta, nk [N, C], csum [C] | None).
+    addend [N,C,H,W]: added to dx in the kernel; nk = sum_hw dx per (image, channel); csum = sum_n nk (returned with
+    `csum=True`, and / or added into `csum_acc`)."""
     N, C, H, W = x.shape
     L = _lib.lib()
     dx = torch.empty_like(x)
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = workspace(L.salun_gn_workspace_bytes(N, C), x.device)
-    check(L.salun_gn_backward(_dev(dz, torch.float32, "dz"), _dev(x, torch.float32, "x"),
-                              _dev(gamma, torch.float32, "weight"), _dev(beta, torch.float32, "bias"),
-                              _dev(mean, torch.float32, "mean"), _dev(rstd, torch.float32, "rstd"),
-                              c_void_p(dx.data_ptr()), c_void_p(dgamma.data_ptr()), c_void_p(dbeta.data_ptr()),
-                              _dev(gamma_grad_acc, torch.float32, "weight.grad", True),
-                              _dev(beta_grad_acc, torch.float32, "bias.grad", True), N, C, H * W, int(groups),
-                              int(bool(silu)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()),
-          "salun_gn_backward")
+    if addend is not None and addend.shape != x.shape:
+        raise ValueError("gn_backward: addend must have the shape of x")
+    want_nk = bool(nk_sum or csum or csum_acc is not None)
+    nk = torch.empty((N, C), dtype=torch.float32, device=x.device) if want_nk else None
+    cs = torch.empty(C, dtype=torch.float32, device=x.device) if csum else None
+    check(L.salun_gn_backward_fused(_dev(dz, torch.float32, "dz"), _dev(x, torch.float32, "x"),
+                                    _dev(gamma, torch.float32, "weight"), _dev(beta, torch.float32, "bias"),
+                                    _dev(mean, torch.float32, "mean"), _dev(rstd, torch.float32, "rstd"),
+                                    _dev(addend, torch.float32, "addend", True),
+                                    c_void_p(dx.data_ptr()), c_void_p(dgamma.data_ptr()), c_void_p(dbeta.data_ptr()),
+                                    _dev(gamma_grad_acc, torch.float32, "weight.grad", True),
+                                    _dev(beta_grad_acc, torch.float32, "bias.grad", True),
+                                    _dev(nk, torch.float32, "nk_sum", True), _dev(cs, torch.float32, "csum", True),
+                                    _dev(csum_acc, torch.float32, "csum_acc", True), N, C, H * W, int(groups),
+                                    int(bool(silu)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()),
+          "salun_gn_backward_fused")
+    if want_nk:
+        return dx, dgamma, dbeta, nk, cs
     return dx, dgamma, dbeta
 
 

@@ -233,3 +233,199 @@ def fused_basic_block(blk, x: torch.Tensor):
     return _BasicBlockFn.apply(x, blk, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight,
                                blk.bn2.weight, blk.bn2.bias, d[0].weight if d is not None else None,
                                d[1].weight if d is not None else None, d[1].bias if d is not None else None)
+
+
+# =====================================================================================================================
+# The diffusion U-Net's ResnetBlock as ONE autograd node (reference block: DDPM/models/diffusion.py:85-128)
+#
+#     h   = conv1(swish(norm1(x))) + proj[:, :, None, None]        proj = Linear(swish([temb | cemb]))  (outside)
+#     out = skip(x) + conv2(dropout(swish(norm2(h))))              skip = identity | 1x1 (nin) | 3x3 convolution
+#
+# Forward: 2 fused GroupNorm+SiLU launches and 2-3 MFMA convolutions whose epilogues carry the two adds (`nbias` = the
+# embedding projection, `addend` = the skip branch) — no element-wise pass over an activation besides dropout.
+# Backward: norm2's backward kernel also emits sum_hw of its dx per (image, channel) — that IS the projection's
+# gradient, and folded over the batch conv1's bias gradient — and norm1's backward adds the skip branch's gradient
+# before its store; conv2's and the skip convolution's bias gradients share one streaming channel sum of dout; weight
+# gradients go to the side stream and straight into `.grad` (gradsink), as for the BasicBlock above.
+class _DiffusionResnetBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, proj, blk, n1w, n1b, w1, b1, n2w, n2b, w2, b2, ws, bs):
+        N, C, H, W = x.shape
+        G1, G2 = blk.norm1.num_groups, blk.norm2.num_groups
+        a1, m1, r1 = ops.gn_forward(x, n1w, n1b, G1, blk.norm1.eps, True)
+        c1 = ops.conv2d_forward(a1, w1, b1, 1, 1, H, W, nbias=proj)
+        a2, m2, r2 = ops.gn_forward(c1, n2w, n2b, G2, blk.norm2.eps, True)
+        p = float(blk.dropout.p) if blk.dropout.training else 0.0
+        keep = None
+        if p > 0.0:
+            a2, keep = torch.native_dropout(a2, p, True)
+        if ws is not None:
+            sc = ops.conv2d_forward(x, ws, bs, 1, (ws.shape[2] - 1) // 2, H, W)
+        else:
+            sc = x
+        out = ops.conv2d_forward(a2, w2, b2, 1, 1, H, W, addend=sc)
+        ctx.save_for_backward(x, a1, c1, a2, keep, n1w, n1b, w1, b1, n2w, n2b, w2, b2, ws, bs, m1, r1, m2, r2)
+        ctx.cfg = (G1, G2, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, a1, c1, a2, keep, n1w, n1b, w1, b1, n2w, n2b, w2, b2, ws, bs, m1, r1, m2, r2 = ctx.saved_tensors
+        G1, G2, p = ctx.cfg
+        dout = dout.contiguous()
+        main = torch.cuda.current_stream(dout.device)
+        side = _side_stream(dout.device) if OVERLAP_WGRAD else None
+        returned = []  # weight gradients handed back to autograd (no sink): they need the main stream to have joined
+
+        def wgrad(xin, dy, w, pad):
+            dst = gradsink.sink(w)
+            if side is None:
+                dw = ops.conv2d_backward_weight(xin, dy, w.shape, 1, pad, out=dst, accumulate=True)
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dw = ops.conv2d_backward_weight(xin, dy, w.shape, 1, pad, out=dst, accumulate=True)
+                for t in (xin, dy):
+                    t.record_stream(side)
+                if dst is None and dw is not None:
+                    dw.record_stream(main)
+            if dst is not None:
+                gradsink.arrived(w)
+                return None
+            returned.append(dw)
+            return dw
+
+        def gn_sinks(g, b):
+            gw, gb = gradsink.sink(g), gradsink.sink(b)
+            return (gw, gb) if gw is not None and gb is not None else (None, None)
+
+        # ---- bias gradients of conv2 and of the skip convolution: one channel sum of dout
+        db2 = dbs = None
+        s2, ss = gradsink.sink(b2), (gradsink.sink(bs) if bs is not None else None)
+        if bs is None and s2 is not None:
+            ops.channel_sum(dout, out=s2, accumulate=True)
+        else:
+            csum = ops.channel_sum(dout)
+            if s2 is not None:
+                s2.add_(csum)
+            else:
+                db2 = csum
+            if bs is not None:
+                if ss is not None:
+                    ss.add_(csum)
+                else:
+                    dbs = csum
+        # ---- conv2
+        dw2 = wgrad(a2, dout, w2, 1)
+        da2 = ops.conv2d_backward_data(dout, w2, a2.shape, 1, 1)
+        if keep is not None:
+            da2 = torch.ops.aten.native_dropout_backward(da2, keep, 1.0 / (1.0 - p))
+        # ---- norm2 (+ SiLU): dx = dc1; its per-(image, channel) sums are dproj, their batch sum conv1's bias gradient
+        gw, gb = gn_sinks(n2w, n2b)
+        s1 = gradsink.sink(b1)
+        dc1, dg2, dbt2, nk, cs = ops.gn_backward(da2, c1, n2w, n2b, m2, r2, G2, True, gw, gb, nk_sum=True,
+                                                 csum=s1 is None, csum_acc=s1)
+        if gw is not None:
+            dg2 = dbt2 = None
+        db1 = cs  # None when it was added into b1.grad by the kernel
+        dproj = nk if ctx.needs_input_grad[1] else None
+        # ---- conv1
+        dw1 = wgrad(a1, dc1, w1, 1)
+        da1 = ops.conv2d_backward_data(dc1, w1, a1.shape, 1, 1)
+        # ---- norm1 (+ SiLU) and the skip branch
+        gw, gb = gn_sinks(n1w, n1b)
+        dws = None
+        if ws is None:
+            dx, dg1, dbt1 = ops.gn_backward(da1, x, n1w, n1b, m1, r1, G1, True, gw, gb, addend=dout)
+        else:
+            pad = (ws.shape[2] - 1) // 2
+            dws = wgrad(x, dout, ws, pad)
+            dxg, dg1, dbt1 = ops.gn_backward(da1, x, n1w, n1b, m1, r1, G1, True, gw, gb)
+            dx = ops.conv2d_backward_data(dout, ws, x.shape, 1, pad, addend=dxg)
+        if gw is not None:
+            dg1 = dbt1 = None
+        if side is not None:
+            if sdist.collectives_on() or returned:
+                main.wait_stream(side)
+            else:
+                _join_at_end_of_backward(dout.device)
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        return dx, dproj, None, dg1, dbt1, dw1, db1, dg2, dbt2, dw2, db2, dws, dbs
+
+
+def _diffusion_block_structure_ok(blk) -> bool:
+    convs = [blk.conv1, blk.conv2]
+    skip = getattr(blk, "conv_shortcut", None) if blk.use_conv_shortcut else getattr(blk, "nin_shortcut", None)
+    if blk.in_channels != blk.out_channels:
+        if skip is None:
+            return False
+        convs.append(skip)
+    if any(type(n) is not nn.GroupNorm or not n.affine or n.weight.dtype != torch.float32
+           for n in (blk.norm1, blk.norm2)):
+        return False
+    for c in convs:
+        if (c.bias is None or c.groups != 1 or c.dilation != (1, 1) or c.stride != (1, 1)
+                or c.padding_mode != "zeros" or c.weight.dtype != torch.float32):
+            return False
+    ok = all(c.kernel_size == (3, 3) and c.padding == (1, 1) for c in (blk.conv1, blk.conv2))
+    if len(convs) == 3:
+        k = convs[2].kernel_size
+        ok = ok and k in ((1, 1), (3, 3)) and convs[2].padding == ((k[0] - 1) // 2,) * 2
+    return ok and type(blk.dropout) is nn.Dropout and 0.0 <= blk.dropout.p < 1.0 and not blk.dropout.inplace
+
+
+def _diffusion_block_probe(blk, shape, device) -> bool:
+    """Dry run of every launch of the node on uninitialised buffers (only the return codes matter)."""
+    N, C, H, W = shape
+    K = blk.out_channels
+    hw = H * W
+    if hw < 4 or hw & (hw - 1) or C // blk.norm1.num_groups > 256 or K // blk.norm2.num_groups > 256:
+        return False
+    e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=device)
+    x, h, proj = e(N, C, H, W), e(N, K, H, W), e(N, K)
+    try:
+        for t, n in ((x, blk.norm1), (h, blk.norm2)):
+            z, m, r = ops.gn_forward(t, n.weight, n.bias, n.num_groups, n.eps, True)
+            ops.gn_backward(z, t, n.weight, n.bias, m, r, n.num_groups, True, addend=t, nk_sum=True)
+    except Exception:
+        return False
+    convs = [(x, blk.conv1), (h, blk.conv2)]
+    if C != K:
+        convs.append((x, blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut))
+    for xin, c in convs:
+        pad = c.padding[0]
+        if ops.conv2d_forward(xin, c.weight, c.bias, 1, pad, H, W, nbias=proj, addend=h) is None:
+            return False
+        if ops.conv2d_backward_data(h, c.weight, xin.shape, 1, pad, addend=xin) is None:
+            return False
+        if ops.conv2d_backward_weight(xin, h, c.weight.shape, 1, pad) is None:
+            return False
+    return True
+
+
+def fused_diffusion_resnet_block(blk, x: torch.Tensor, emb_act: torch.Tensor):
+    """`blk(x, emb_act)` as one autograd node, or None when the block cannot take this path (the module then runs
+    its ordinary forward)."""
+    from . import norm
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) or torch.is_autocast_enabled() or not norm._FUSED_GN:
+        return None
+    cache = blk.__dict__.setdefault("_fused_shapes", {})
+    key = (tuple(x.shape), x.device)
+    ok = cache.get(key)
+    if ok is None:
+        with torch.no_grad():
+            ok = cache[key] = _diffusion_block_structure_ok(blk) and _diffusion_block_probe(blk, tuple(x.shape), x.device)
+    if not ok or not _diffusion_block_structure_ok(blk):
+        return None
+    proj = blk.temb_cemb_proj(emb_act)
+    if proj.dtype != torch.float32 or tuple(proj.shape) != (x.shape[0], blk.out_channels):
+        return None
+    skip = None
+    if blk.in_channels != blk.out_channels:
+        skip = blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut
+    return _DiffusionResnetBlockFn.apply(x.contiguous(), proj.contiguous(), blk, blk.norm1.weight, blk.norm1.bias,
+                                         blk.conv1.weight, blk.conv1.bias, blk.norm2.weight, blk.norm2.bias,
+                                         blk.conv2.weight, blk.conv2.bias,
+                                         skip.weight if skip is not None else None,
+                                         skip.bias if skip is not None else None)

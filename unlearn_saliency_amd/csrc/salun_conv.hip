@@ -35,6 +35,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CC = 8;  // reduction channels staged per chunk
+// conv_igemm's chunk: a 1x1 stride-1 convolution has one MFMA step per two channels, so an 8-channel chunk is four
+// steps between two barrier pairs (72 TFLOP/s on the DDPM attention / skip projections); 32 channels make it sixteen.
+constexpr int igemm_chunk(int R, int stride) { return (R == 1 && stride == 1) ? 32 : CC; }
 
 // Tuning switches (0 in the product build; tools/_run_wgrad_exp.sh / _run_igemm_exp.sh build A/B libraries with them
 // to see where a kernel's time goes — results are WRONG with any bit set; DESIGN.md §6 has the round-3 table):
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
                                                   const float *__restrict__ addend /*forward: [N][yC][yH][yW] or null*/) {
   constexpr int RS = R * R;
   constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
+  constexpr int CC = igemm_chunk(R, STRIDE);  // (shadows the file-wide 8)
   constexpr int WROW = CC * RS + 1;    // LDS weight row (odd => conflict-free across 32 rows)
   constexpr int CONV_S = DGRAD ? 1 : STRIDE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__r
   }
 
   // ---- the (<= 3) patch positions this thread stages for every channel of a chunk
-  constexpr int MAXPOS = 3;
+  constexpr int MAXPOS = (R == 1 && STRIDE == 1) ? 1 : 3;  // 1x1 stride 1: the patch IS the pixel tile (<= 256)
   PatchPos pos[MAXPOS];
   const int planeHW = xH * xW;
   // virtual (possibly upsampled) input extent
@@ -1779,6 +1783,7 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
   const int PSZ = g.NI * g.IH_t * g.IW_t;
   const int ch_stride = PSZ | 1;
   constexpr int RS = R * R;
+  constexpr int CC = igemm_chunk(R, STRIDE);  // the kernel's chunk (shadows the file-wide 8)
 #define SALUN_IGEMM(KT_, WP_, WK_)                                                                              \
   {                                                                                                             \
     constexpr int KB = WK_ * KT_ * 32;                                                                          \

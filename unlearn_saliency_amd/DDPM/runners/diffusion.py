@@ -41,6 +41,18 @@ from ..models.diffusion import Conditional_Model
 DP_PREFIX = "module."  # reference checkpoints / masks come from nn.DataParallel-wrapped models
 
 
+# SALUN_DDPM_TARGET_OVERLAP=0: run the RL method's no-grad target pass on the main stream, after the forget pass
+PSEUDO_OVERLAP = os.environ.get("SALUN_DDPM_TARGET_OVERLAP", "1") != "0"
+_target_streams: dict = {}
+
+
+def _target_stream(device) -> "torch.cuda.Stream":
+    s = _target_streams.get(device)
+    if s is None:
+        s = _target_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_timesteps):
     """float64 numpy β_1..β_T (reference :36-66)."""
     T = num_diffusion_timesteps
@@ -225,16 +237,32 @@ class Diffusion(object):
         forget_weight = draws.weight
         if args.method == "ga":
             forget_loss = -loss_registry_conditional[config.model.type](model, forget_x, t, forget_c, e, b)
-        else:
+        elif args.method == "rl":
             xt = q_sample(forget_x, t, e, b)
-            output = model(xt, t.float(), forget_c, mode="train")
-            if args.method == "rl":
-                pseudo_c = torch.full(forget_c.shape, (args.label_to_forget + 1) % 10, device=forget_c.device)
-                with torch.no_grad():
-                    pseudo = model(xt, t.float(), pseudo_c, mode="train")
-                forget_loss = ops.mse_loss(pseudo, output)
+            pseudo_c = torch.full(forget_c.shape, (args.label_to_forget + 1) % 10, device=forget_c.device)
+            tf = t.float()
+            side = _target_stream(xt.device) if (PSEUDO_OVERLAP and xt.is_cuda) else None
+            if side is not None:
+                # the no-grad target pass depends only on (xt, t): it runs on its own stream NEXT TO the forward pass
+                # that is differentiated, filling the phases where one pass leaves the chip half empty (4x4 / 8x8
+                # levels, 1x1 projections, GroupNorm, attention).  Host call order — hence the order in which dropout /
+                # conditioning-drop draws are taken — is unchanged: `output` first, then the target.
+                main = torch.cuda.current_stream(xt.device)
+                side.wait_stream(main)
+            output = model(xt, tf, forget_c, mode="train")
+            if side is not None:
+                with torch.no_grad(), torch.cuda.stream(side):
+                    pseudo = model(xt, tf, pseudo_c, mode="train")
+                for v in (xt, tf, pseudo_c):
+                    v.record_stream(side)
+                main.wait_stream(side)
+                pseudo.record_stream(main)
             else:
-                raise ValueError(f"unknown --method {args.method!r} (rl | ga)")
+                with torch.no_grad():
+                    pseudo = model(xt, tf, pseudo_c, mode="train")
+            forget_loss = ops.mse_loss(pseudo, output)
+        else:
+            raise ValueError(f"unknown --method {args.method!r} (rl | ga)")
         if forget_weight != 1.0:
             forget_loss = forget_loss * forget_weight
         loss = forget_loss + args.alpha * remain_loss

@@ -48,6 +48,9 @@ constexpr int igemm_chunk(int R, int stride) { return (R == 1 && stride == 1) ? 
 #ifndef SALUN_WGRAD_EXP
 #define SALUN_WGRAD_EXP 0
 #endif
+#ifndef SALUN_IGEMM_OCC
+#define SALUN_IGEMM_OCC 2  // waves per SIMD the FAST conv_igemm instantiations are compiled for (A/B: 3)
+#endif
 #ifndef SALUN_IGEMM_EXP
 #define SALUN_IGEMM_EXP 0
 #endif
@@ -97,7 +100,7 @@ struct PatchPos {
 // `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
 // STRIDE and the padding is R-1-pad.
 template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST, int PT = 1>
-__global__ __launch_bounds__(256, FAST ? 2 : 1) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
+__global__ __launch_bounds__(256, FAST ? SALUN_IGEMM_OCC : 1) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
                                                   const float *__restrict__ bias, float *__restrict__ y, int N,
                                                   int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
                                                   int TP, int IH_t, int IW_t, int logQ, int wC /*w dim1 (C of OIHW)*/,

@@ -96,9 +96,7 @@ def test_sd_v1_bf16_full_size_unlearn_step():
     t = torch.randint(0, model.num_timesteps, (B,), device=dev).long()
     noise = torch.randn_like(z_f)
     z_noisy = model.q_sample(x_start=z_f, t=t, noise=noise)
-    forget_out = model.apply_model(z_noisy, t, c_f)
-    with torch.no_grad():
-        pseudo_out = model.apply_model(z_noisy, t, c_p)
+    forget_out, pseudo_out = TS.forget_and_target(model, z_noisy, t, c_f, c_p)  # target pass on a second stream
     loss = ops.mse_loss(pseudo_out, forget_out) + 0.1 * remain_loss
     loss.backward()
     opt.step()

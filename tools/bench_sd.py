@@ -106,9 +106,7 @@ def main(argv=None):
             t = torch.randint(0, model.num_timesteps, (B,), device=dev).long()
             noise = torch.randn_like(z_f)
             z_noisy = model.q_sample(x_start=z_f, t=t, noise=noise)
-            forget_out = model.apply_model(z_noisy, t, c_f)
-            with torch.no_grad():
-                pseudo_out = model.apply_model(z_noisy, t, c_p)
+            forget_out, pseudo_out = TS.forget_and_target(model, z_noisy, t, c_f, c_p)
             loss = ops.mse_loss(pseudo_out, forget_out) + 0.1 * remain_loss
             loss.backward()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -114,6 +114,43 @@ def generate_nsfw_mask(c_guidance, batch_size, epochs, lr, config_path, ckpt_pat
     return mask
 
 
+# SALUN_SD_TARGET_OVERLAP=0: run the no-grad target pass on the main stream, after the forget pass
+TARGET_OVERLAP = os.environ.get("SALUN_SD_TARGET_OVERLAP", "1") != "0"
+_target_streams: dict = {}
+
+
+def forget_and_target(model, z_noisy, t, c_forget, c_target):
+    """`forget_out = eps(z_t, t, c_forget)` (differentiated) and `target = eps(z_t, t, c_target)` under no_grad — the
+    two U-Net passes of nsfw_removal.py:131-140 / random_label.py:112-121.  They depend on nothing of each other, and
+    at batch 8 most of the U-Net's kernels leave the chip partly empty, so on the device the target pass is issued on a
+    second stream beside the forget pass.  Host call order (forget first) is the reference's.  Safe only while no
+    cached weight image is (re)written during the two passes: the packed bf16 weights are produced by the first pass
+    after an optimizer step — the remain pass, in every loop of this file; if the forget pass had to pack anything
+    (cold cache) the target pass is issued on the main stream after it instead."""
+    dev = z_noisy.device
+    if not (TARGET_OVERLAP and z_noisy.is_cuda):
+        out = model.apply_model(z_noisy, t, c_forget)
+        with torch.no_grad():
+            return out, model.apply_model(z_noisy, t, c_target)
+    side = _target_streams.get(dev)
+    if side is None:
+        side = _target_streams[dev] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    side.wait_stream(main)
+    packs = ops.PACK_CALLS[0]
+    out = model.apply_model(z_noisy, t, c_forget)
+    if ops.PACK_CALLS[0] != packs:
+        with torch.no_grad():
+            return out, model.apply_model(z_noisy, t, c_target)
+    with torch.no_grad(), torch.cuda.stream(side):
+        target = model.apply_model(z_noisy, t, c_target)
+    for v in (z_noisy, t, c_target):
+        v.record_stream(side)
+    main.wait_stream(side)
+    target.record_stream(main)
+    return out, target
+
+
 def _trainable_mask(arena: FlatArena, train_method: str) -> Optional[torch.Tensor]:
     """"xattn": only parameters whose name contains attn2 are optimised (random_label.py:47-54).  Expressed as a
     u8 mask over the flat arena so the same fused kernel serves both methods."""
@@ -164,9 +201,7 @@ def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_me
             t = torch.randint(0, model.num_timesteps, (z_f.shape[0],), device=model.device).long()
             noise = torch.randn_like(z_f)
             z_noisy = model.q_sample(x_start=z_f, t=t, noise=noise)
-            forget_out = model.apply_model(z_noisy, t, c_forget)
-            with torch.no_grad():
-                pseudo_out = model.apply_model(z_noisy, t, c_pseudo)
+            forget_out, pseudo_out = forget_and_target(model, z_noisy, t, c_forget, c_pseudo)
             loss = ops.mse_loss(pseudo_out, forget_out) + alpha * remain_loss
             loss.backward()
             opt.step()

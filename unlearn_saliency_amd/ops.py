@@ -336,9 +336,15 @@ def conv2d_bf16_supported(C: int, K: int, R: int, stride: int, pad: int) -> bool
     return bool(_lib.lib().salun_conv2d_bf16_supported(C, K, R, stride, pad))
 
 
+# number of weight re-packs issued so far (SD/train_scripts.py::forget_and_target uses it to detect cold caches: a pack
+# kernel enqueued on one stream while another stream is about to read the same image)
+PACK_CALLS = [0]
+
+
 def conv2d_bf16_pack(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 OIHW master weights -> the bf16 image [K, R*R, C] the forward and backward-data kernels read."""
     K, C, R, _ = w.shape
+    PACK_CALLS[0] += 1
     if out is None:
         out = torch.empty((K, R * R, C), dtype=torch.bfloat16, device=w.device)
     check(_lib.lib().salun_conv2d_bf16_pack_weights(_dev(w, torch.float32, "w"), _dev(out, torch.bfloat16, "wp"), K, C, R,

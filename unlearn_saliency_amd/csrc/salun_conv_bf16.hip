@@ -24,6 +24,7 @@
 // Workgroup = 4 or 8 waves, each wave a 64x64 result tile (2x2 MFMA tiles, 64 fp32 accumulators); LDS double
 // buffered, global loads of stage i+1 in flight under the MFMAs of stage i, one barrier per stage.
 #include "salun_common.h"
+#include <cstdlib>
 
 #ifndef SALUN_BF16_TILE
 #define SALUN_BF16_TILE 0  // lab builds (tools/_run_bf16_lab.sh) pin one tile shape; 0 = choose per problem
@@ -537,8 +538,11 @@ __global__ __launch_bounds__(256) void k_colsum_finish(const float *__restrict__
 }
 
 int wgrad_splits(int tiles, int chunks) {
-  // about two resident rounds of workgroups (LDS admits 2-3 per CU), never more splits than chunks
-  int s = (768 + tiles - 1) / tiles;
+  // about 1.5 workgroups per CU, never more splits than chunks
+  // measured on the SD-v1 step (tools/_run_block5.sh, round 3): 1536 / 768 / 384 / 256 target workgroups ->
+  // 219.3 / 209.3 / 205.7 / 206.6 ms — every split adds a K*C*R*R fp32 partial to write and re-read (59 MB for a
+  // 1280x1280 3x3 layer), which costs more than the second resident round of workgroups gives back
+  int s = (384 + tiles - 1) / tiles;
   if (s > chunks) s = chunks;
   if (s > 64) s = 64;
   if (s < 1) s = 1;

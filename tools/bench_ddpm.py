@@ -153,6 +153,8 @@ def main(argv=None):
     samples = 0
     torch.cuda.synchronize()
     sdist.barrier()
+    if os.environ.get("SALUN_SYNC_DEBUG"):  # diagnostics: warn on every host-synchronising call inside the timed steps
+        torch.cuda.set_sync_debug_mode(1)
     t3 = time.perf_counter()
     for i in range(a.steps):
         # events bracket the optimizer tail ([all-reduce join] + sq-norm + masked Adam) by patching step()
@@ -163,6 +165,7 @@ def main(argv=None):
         samples += rb[0].size(0)
         runner.unlearn_step(model, opt, rb, fb_)
     opt.step = real_step
+    host_enqueue_s = time.perf_counter() - t3  # the host has issued every step; the device may still be running
     torch.cuda.synchronize()
     sdist.barrier()
     dt = time.perf_counter() - t3
@@ -194,6 +197,7 @@ def main(argv=None):
                           "parallelism": f"dp{world}",
                           "library_conv_calls": dict(sconv.LIBRARY_CONV_CALLS, total=sconv.library_conv_calls())},
                "samples_per_sec": samples / dt,
+               "host_enqueue_ms_per_step": 1e3 * host_enqueue_s / a.steps,
                "mask_gen": {"batches": a.mask_batches, "saliency_sec": t1 - t0, "topk_sec": t2 - t1},
                "roofline": {"kernel": "salun_grad_sqnorm + salun_masked_adam_step"
                                       + ("" if not sdist.collectives_on() else " (+ gradient-bucket join)"),

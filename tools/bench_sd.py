@@ -122,8 +122,11 @@ def main(argv=None):
     run(a.warmup)
     torch.cuda.synchronize()
     sdist.barrier()
+    if os.environ.get("SALUN_SYNC_DEBUG"):  # diagnostics: warn on every host-synchronising call inside the timed steps
+        torch.cuda.set_sync_debug_mode(1)
     t0 = time.perf_counter()
     tail = run(a.steps)
+    host_enqueue_s = time.perf_counter() - t0  # the host has issued every step; the device may still be running
     torch.cuda.synchronize()
     sdist.barrier()
     dt = (time.perf_counter() - t0) / a.steps
@@ -138,7 +141,7 @@ def main(argv=None):
         "metric": "sd_unlearn_steps_per_sec (SD-v1 U-Net nsfw_removal body, batch 8, 64x64 latents)",
         "value": world / dt, "unit": "steps/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
         "backend": (torch.distributed.get_backend() if sdist.is_dist() else "single-process"),
-        "ms_per_step": dt * 1e3, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": 1e3 * host_enqueue_s / a.steps, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "config": {"workload": "Stable Diffusion v1 LDM U-Net (859,520,964 params), nsfw_removal loop body "
                                "(SD/train-scripts/nsfw_removal.py:33-175): remain pass + forget pass + pseudo pass, "

@@ -74,7 +74,13 @@ def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_time
 
 def antithetic_timesteps(n: int, num_timesteps: int, device) -> torch.Tensor:
     """t ~ randint(T) for n//2+1 draws, mirrored with T-t-1, truncated to n (reference :530-533)."""
-    t = torch.randint(low=0, high=num_timesteps, size=(n // 2 + 1,)).to(device)
+    t = torch.randint(low=0, high=num_timesteps, size=(n // 2 + 1,))  # host generator, as the reference draws them
+    if torch.device(device).type == "cuda":
+        # pinned + non_blocking: a pageable host-to-device copy blocks the host until everything queued before it has
+        # run — twice per unlearning step, which kept the host from ever running ahead of the device
+        t = t.pin_memory().to(device, non_blocking=True)
+    else:
+        t = t.to(device)
     return torch.cat([t, num_timesteps - t - 1], dim=0)[:n]
 
 

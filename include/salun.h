@@ -235,7 +235,17 @@ int salun_conv2d_forward(const float *x /*dev*/, const float *w /*dev*/, const f
 int salun_conv2d_forward_fused(const float *x /*dev*/, const float *w /*dev*/, const float *bias /*dev or NULL*/,
                                const float *nbias /*dev [N,K] or NULL*/, const float *addend /*dev [N,K,P,Q] or NULL*/,
                                float *y /*dev*/, int N, int C, int H, int W, int K, int R, int stride, int pad,
-                               int P, int Q, salun_stream_t stream);
+                               int P, int Q, void *ws /*dev or NULL*/, size_t ws_bytes, salun_stream_t stream);
+/* Under-filled launches (an output small enough for <= 256 workgroups, e.g. the 4x4 level of the DDPM U-Net: half the
+ * CUs idle) are split over the reduction channels when a workspace is passed: S <= 8 workgroups per output tile write
+ * partial images, a second small kernel adds them in fixed order together with the epilogue terms (deterministic; the
+ * rounding differs from the unsplit launch's).  salun_conv2d_data_workspace_bytes: bytes for an OUTPUT of
+ * [N, outC, outH, outW] (forward: K, P, Q and the forward stride; backward-data: C, H, W and conv_stride 1); 0 when
+ * the launch would not be split.  ws == NULL: never split. */
+size_t salun_conv2d_data_workspace_bytes(int N, int outC, int outH, int outW, int R, int conv_stride);
+int salun_conv2d_backward_data_ws(const float *dy /*dev*/, const float *w /*dev*/, const float *addend /*dev or NULL*/,
+                                  float *dx /*dev*/, int N, int C, int H, int W, int K, int R, int stride, int pad,
+                                  int P, int Q, void *ws /*dev or NULL*/, size_t ws_bytes, salun_stream_t stream);
 int salun_conv2d_backward_data(const float *dy /*dev*/, const float *w /*dev*/, float *dx /*dev*/, int N, int C,
                                int H, int W, int K, int R, int stride, int pad, int P, int Q,
                                salun_stream_t stream);

@@ -32,7 +32,10 @@ def rel(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("shape", [(4, 64, 96, 3, 16), (3, 128, 128, 3, 8), (4, 96, 64, 1, 16), (130, 128, 128, 3, 4)])
+# (128, 256, 256, 3, 4) and (128, 512, 256, 3, 4): the 4x4 level of the DDPM U-Net at batch 128 — 128 workgroups, run
+# with the reduction split (four workgroups per output tile + the finishing kernel carrying the epilogue terms)
+@pytest.mark.parametrize("shape", [(4, 64, 96, 3, 16), (3, 128, 128, 3, 8), (4, 96, 64, 1, 16), (130, 128, 128, 3, 4),
+                                   (128, 256, 256, 3, 4), (128, 512, 256, 3, 4), (128, 256, 256, 1, 4)])
 def test_forward_epilogue_bias_nbias_addend(shape):
     from unlearn_saliency_amd import ops
     N, C, K, R, H = shape
@@ -91,6 +94,30 @@ def test_gn_backward_fused_outputs(shape, silu):
     _, _, _, nk2, cs2 = ops.gn_backward(dz, x, g, b, m, r, 32, silu, nk_sum=True)
     assert cs2 is None
     assert float((nk2.double() - dx0.double().sum(dim=(2, 3))).abs().max()) <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("shape", [(128, 256, 256, 3, 4), (128, 512, 256, 3, 4), (128, 256, 256, 1, 4), (16, 128, 128, 3, 8)])
+def test_reduction_split_backward_data_and_workspace(shape):
+    """Stride-1 backward-data of an under-filled launch (split over the reduction channels) against float64, with and
+    without the addend (also in place: addend is dx), and the workspace query that announces the split."""
+    from unlearn_saliency_amd import _lib, ops
+    N, C, K, R, H = shape
+    pad = (R - 1) // 2
+    L = _lib.lib()
+    assert L.salun_conv2d_data_workspace_bytes(N, C, H, H, R, 1) == 8 * N * C * H * H * 4
+    assert L.salun_conv2d_data_workspace_bytes(256, 64, 32, 32, 3, 1) == 0      # a full launch is never split
+    w, dy, ad = dev_normal((K, C, R, R), 41, 0.05), dev_normal((N, K, H, H), 42), dev_normal((N, C, H, H), 43)
+    want = torch.nn.grad.conv2d_input((N, C, H, H), w.double(), dy.double(), 1, pad)
+    dx = ops.conv2d_backward_data(dy, w, (N, C, H, H), 1, pad)
+    assert rel(dx, want) <= TOL
+    dxa = ops.conv2d_backward_data(dy, w, (N, C, H, H), 1, pad, addend=ad)
+    assert rel(dxa, want + ad.double()) <= TOL and torch.equal(dxa, dx + ad)
+    # the unsplit launch (no workspace through the legacy entry point) agrees to rounding
+    from ctypes import c_void_p
+    dx0 = torch.empty_like(dx)
+    assert L.salun_conv2d_backward_data(c_void_p(dy.data_ptr()), c_void_p(w.data_ptr()), c_void_p(dx0.data_ptr()), N, C, H,
+                                        H, K, R, 1, pad, H, H, c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    assert rel(dx0, want) <= TOL and rel(dx, dx0) <= TOL
 
 
 class _FixedMaskDropout(torch.nn.Dropout):

@@ -57,7 +57,9 @@ SIGNATURES = {
                                  c_void_p, c_size_t, c_void_p]),
     "salun_fim_square_accumulate": (c_int, [c_void_p, c_void_p, c_double, c_int64, c_void_p]),
     "salun_conv2d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
-    "salun_conv2d_forward_fused": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),
+    "salun_conv2d_forward_fused": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
+    "salun_conv2d_data_workspace_bytes": (c_size_t, [c_int] * 6),
+    "salun_conv2d_backward_data_ws": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_backward_data": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "salun_channel_sum_workspace_bytes": (c_size_t, [c_int] * 2),
     "salun_channel_sum": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),

@@ -99,13 +99,14 @@ struct PatchPos {
 // `x` is the tensor the patch is read from (forward: input; DGRAD: dY), `y` the tensor written.
 // `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
 // STRIDE and the padding is R-1-pad.
-template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST, int PT = 1>
+template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST, int PT = 1, bool SPLIT = false>
 __global__ __launch_bounds__(256, FAST ? SALUN_IGEMM_OCC : 1) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
                                                   const float *__restrict__ bias, float *__restrict__ y, int N,
                                                   int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
                                                   int TP, int IH_t, int IW_t, int logQ, int wC /*w dim1 (C of OIHW)*/,
                                                   int wK /*w dim0*/, const float *__restrict__ nbias /*[N][yC] or null*/,
-                                                  const float *__restrict__ addend /*forward: [N][yC][yH][yW] or null*/) {
+                                                  const float *__restrict__ addend /*forward: [N][yC][yH][yW] or null*/,
+                                                  int csplit /*reduction channels per blockIdx.z (0: no split)*/) {
   constexpr int RS = R * R;
   constexpr int KB = WK * KT * 32;     // output channels per workgroup tile
   constexpr int CC = igemm_chunk(R, STRIDE);  // (shadows the file-wide 8)
@@ -181,7 +182,13 @@ __global__ __launch_bounds__(256, FAST ? SALUN_IGEMM_OCC : 1) void conv_igemm(co
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[pt][t][v] = 0.f;
 
-  const int Cred = xC;  // reduction channels = channels of the tensor the patch is read from
+  // reduction channels = channels of the tensor the patch is read from; with a reduction split (under-filled launches:
+  // launch_igemm) workgroup z covers [z * csplit, (z+1) * csplit) and writes a partial output image (no epilogue terms)
+  // (SPLIT is a template parameter: the extra address arithmetic cost the unsplit instantiations 1.5 % of the ResNet-18
+  // step when it was a run-time branch — measured on the same box, tools/_run_ab_tree.sh)
+  const int cz0 = SPLIT ? (int)blockIdx.z * csplit : 0;
+  const int Cred = SPLIT ? ((cz0 + csplit < xC) ? cz0 + csplit : xC) : xC;
+  if (SPLIT) y += (size_t)blockIdx.z * ((size_t)N * yC * yH * yW);
   // Register-staged software pipeline: the global loads of chunk i+1 are issued before the MFMA section of
   // chunk i and only consumed (written to LDS) after it, so their latency hides under the matrix work.
   constexpr int WN = KB * CC * RS / 256;  // weight-slab elements per thread per chunk (KB*RS/32)
@@ -291,11 +298,11 @@ __global__ __launch_bounds__(256, FAST ? SALUN_IGEMM_OCC : 1) void conv_igemm(co
     }
   };
 
-  load_chunk(0);
-  for (int c0 = 0; c0 < Cred; c0 += CC) {
-    if (!(SALUN_IGEMM_EXP & 4) || c0 == 0) __syncthreads();  // previous chunk fully consumed
-    if (!(SALUN_IGEMM_EXP & 2) || c0 == 0) store_chunk();
-    if (!(SALUN_IGEMM_EXP & 4) || c0 == 0) __syncthreads();
+  load_chunk(cz0);
+  for (int c0 = cz0; c0 < Cred; c0 += CC) {
+    if (!(SALUN_IGEMM_EXP & 4) || c0 == cz0) __syncthreads();  // previous chunk fully consumed
+    if (!(SALUN_IGEMM_EXP & 2) || c0 == cz0) store_chunk();
+    if (!(SALUN_IGEMM_EXP & 4) || c0 == cz0) __syncthreads();
     if (c0 + CC < Cred && !(SALUN_IGEMM_EXP & 1)) load_chunk(c0 + CC);  // in flight during the MFMA section below
     // ---- MFMA over the chunk: 2 reduction channels per instruction (lanes 0-31: cc, lanes 32-63: cc+1).
     // The (1 + KT) LDS operands of k-step i+1 are read while the KT MFMAs of k-step i run (one-step-ahead
@@ -1769,10 +1776,44 @@ inline TileGeom make_geom(int N, int P, int Q, int pixt, int cs, int R) {
   return g;
 }
 
+// Second half of a reduction-split launch: y = sum_z part[z] (fixed order) + the epilogue terms the split workgroups
+// left out.  `full` is the backward-data addend (same shape as y), or null.
+__global__ __launch_bounds__(256) void conv_split_finish(const float *__restrict__ part, int S, size_t out_elems,
+                                                         const float *__restrict__ bias, const float *__restrict__ nbias,
+                                                         const float *__restrict__ addend, const float *full,
+                                                         float *y, int yC, int HW) {
+  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t e = i4 * 4;
+  if (e >= out_elems) return;
+  float4 acc = *reinterpret_cast<const float4 *>(part + e);
+  for (int z = 1; z < S; ++z) {
+    const float4 p = *reinterpret_cast<const float4 *>(part + (size_t)z * out_elems + e);
+    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+  }
+  const size_t nk = e / (size_t)HW;  // HW % 4 == 0: the four elements share (n, k)
+  if (bias) { const float b = bias[nk % (size_t)yC]; acc.x += b; acc.y += b; acc.z += b; acc.w += b; }
+  if (nbias) { const float b = nbias[nk]; acc.x += b; acc.y += b; acc.z += b; acc.w += b; }
+  if (addend) { const float4 a = *reinterpret_cast<const float4 *>(addend + e); acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+  if (full) { const float4 a = *reinterpret_cast<const float4 *>(full + e); acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+  *reinterpret_cast<float4 *>(y + e) = acc;
+}
+
+// Reduction split for under-filled launches (the 4x4 level of the DDPM U-Net at batch 128 is 128 workgroups of
+// 64 pixels x 64 channels: half the CUs idle, the rest with one workgroup and nothing to hide its staging behind):
+// S workgroups per output tile, each over C/S reduction channels, partial images in the caller's workspace.
+inline int igemm_split(int wgs, int xC, int chunk, size_t out_elems, int HW, const void *ws, size_t ws_bytes) {
+  if (!ws || wgs > 256 || HW % 4 != 0 || out_elems % 4 != 0) return 1;
+  int S = 512 / (wgs < 1 ? 1 : wgs);
+  if (S > 8) S = 8;
+  while (S > 1 && (xC % (S * chunk) != 0 || xC / S < 4 * chunk)) --S;  // equal shares, >= 4 chunks each
+  while (S > 1 && (size_t)S * out_elems * sizeof(float) > ws_bytes) --S;
+  return S < 1 ? 1 : S;
+}
+
 template <int R, int STRIDE, bool DGRAD>
 int launch_igemm(const float *x, const float *w, const float *bias, float *y, int N, int xC, int xH, int xW, int yC,
                  int yH, int yW, int pad, int wC, int wK, hipStream_t st, const float *nbias = nullptr,
-                 const float *addend = nullptr) {
+                 const float *addend = nullptr, void *ws = nullptr, size_t ws_bytes = 0) {
   // tile shape: prefer 128 pixels x up to 128 channels; shrink when that leaves the chip under-filled
   const int cs = DGRAD ? 1 : STRIDE;
   int pixt = 128;
@@ -1787,7 +1828,9 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
   const int ch_stride = PSZ | 1;
   constexpr int RS = R * R;
   constexpr int CC = igemm_chunk(R, STRIDE);  // the kernel's chunk (shadows the file-wide 8)
-#define SALUN_IGEMM(KT_, WP_, WK_)                                                                              \
+  const size_t out_elems = (size_t)N * yC * yH * yW;
+  float *part = static_cast<float *>(ws);
+#define SALUN_IGEMM(KT_, WP_, WK_, SPL_)                                                                        \
   {                                                                                                             \
     constexpr int KB = WK_ * KT_ * 32;                                                                          \
     const size_t ldsb = sizeof(float) * ((size_t)CC * ch_stride + (size_t)KB * (CC * RS + 1));                  \
@@ -1796,19 +1839,35 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
     const bool fast = (xC % CC == 0) && (!DGRAD || yC % KB == 0) && salun_aligned16(w) &&                       \
                       ((wC * RS) % 4 == 0) && !(DGRAD && STRIDE > 1);                                           \
     if (fast) {                                                                                                 \
-      allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>, ldsb);                                       \
-      hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>), grid, dim3(256), ldsb, st, x, w,  \
-                         bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK,   \
-                         nbias, addend);                                                                        \
+      int S = 1;                                                                                                \
+      if constexpr (SPL_) S = igemm_split((int)(grid.x * grid.y), xC, CC, out_elems, yH * yW, ws, ws_bytes);    \
+      if (S > 1) {                                                                                              \
+        if constexpr (SPL_) {                                                                                   \
+          grid.z = S;                                                                                           \
+          allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true, 1, true>, ldsb);                          \
+          hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true, 1, true>), grid, dim3(256), ldsb, \
+                             st, x, w, nullptr, part, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t,       \
+                             g.IW_t, g.logQ, wC, wK, nullptr, nullptr, xC / S);                                 \
+          SALUN_LAUNCH_CHECK();                                                                                 \
+          hipLaunchKernelGGL(conv_split_finish, dim3((unsigned)((out_elems / 4 + 255) / 256)), dim3(256), 0,    \
+                             st, part, S, out_elems, DGRAD ? nullptr : bias, nbias, addend,                     \
+                             DGRAD ? bias : nullptr, y, yC, yH * yW);                                           \
+        }                                                                                                       \
+      } else {                                                                                                  \
+        allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>, ldsb);                                     \
+        hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>), grid, dim3(256), ldsb, st, x, w, \
+                           bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK, \
+                           nbias, addend, 0);                                                                   \
+      }                                                                                                         \
     } else {                                                                                                    \
       allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, false>, ldsb);                                      \
       hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, false>), grid, dim3(256), ldsb, st, x, w, \
                          bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK,   \
-                         nbias, addend);                                                                        \
+                         nbias, addend, 0);                                                                     \
     }                                                                                                           \
   }
   if (pixt == 128) {
-    if (yC > 64) SALUN_IGEMM(4, 4, 1)
+    if (yC > 64) SALUN_IGEMM(4, 4, 1, false)
     else if (yC > 32) {
       // 64 output channels: a wave takes 64 pixels x 64 channels (PT = 2) when 256-pixel tiles still fill the chip
       // and the stride-1 fast path applies
@@ -1823,14 +1882,14 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
         allow_lds(conv_igemm<R, STRIDE, 2, 4, 1, DGRAD, true, 2>, ldsb2);
         hipLaunchKernelGGL((conv_igemm<R, STRIDE, 2, 4, 1, DGRAD, true, 2>), grid2, dim3(256), ldsb2, st, x, w, bias, y,
                            N, xC, xH, xW, yC, yH, yW, pad, g256.NI, g256.TP, g256.IH_t, g256.IW_t, g256.logQ, wC, wK, nbias,
-                           addend);
-      } else SALUN_IGEMM(2, 4, 1)
+                           addend, 0);
+      } else SALUN_IGEMM(2, 4, 1, false)
     }
-    else SALUN_IGEMM(1, 4, 1)
+    else SALUN_IGEMM(1, 4, 1, false)
   } else {
     // small pixel space (deep layers): 64 x 128 tiles only if that still yields enough workgroups
-    if (yC > 64 && g.ntiles * kblocks128 >= 384) SALUN_IGEMM(2, 2, 2)
-    else SALUN_IGEMM(1, 2, 2)
+    if (yC > 64 && g.ntiles * kblocks128 >= 384) SALUN_IGEMM(2, 2, 2, false)
+    else SALUN_IGEMM(1, 2, 2, true)  // the only tiling an under-filled launch ends up with
   }
 #undef SALUN_IGEMM
   SALUN_LAUNCH_CHECK();
@@ -1940,7 +1999,7 @@ int launch_dgrad_s2_merged(const float *dy, const float *w, const float *addend,
 // backward-data: one launch for stride 1, one launch per output parity class for stride 2
 template <int R>
 int launch_dgrad(const float *dy, const float *w, const float *addend, float *dx, int N, int C, int H, int W, int K,
-                 int stride, int pad, int P, int Q, hipStream_t st) {
+                 int stride, int pad, int P, int Q, hipStream_t st, void *ws = nullptr, size_t ws_bytes = 0) {
   IgemmArgs a{};
   a.x = dy; a.w = w; a.bias = addend; a.y = dx;
   a.N = N; a.xC = K; a.xH = P; a.xW = Q; a.yC = C; a.yH = H; a.yW = W;
@@ -1948,7 +2007,7 @@ int launch_dgrad(const float *dy, const float *w, const float *addend, float *dx
   if (stride == 1) {
     a.subH = H; a.subW = W; a.os = 1; a.ph = a.pw = 0;
     a.rtop_h = a.rtop_w = R - 1; a.ts = 1;
-    return launch_igemm<R, 1, true>(dy, w, addend, dx, N, K, P, Q, C, H, W, pad, C, K, st);
+    return launch_igemm<R, 1, true>(dy, w, addend, dx, N, K, P, Q, C, H, W, pad, C, K, st, nullptr, nullptr, ws, ws_bytes);
   }
   if ((H & 1) || (W & 1)) return SALUN_EINVAL;
   {
@@ -2018,44 +2077,79 @@ inline int wgrad_nsplit(int K, int C, int nchunks) {
   return ns;
 }
 
+// workgroups launch_igemm would start for an output of [N, outC, outH, outW] (mirrors its tile choice); -1: outside
+// the tiling domain
+inline int igemm_wgs(int N, int outC, int outH, int outW, int cs, int R) {
+  TileGeom g = make_geom(N, outH, outW, 128, cs, R);
+  const int kblocks128 = (outC + 127) / 128;
+  int pixt = 128;
+  if (!g.ok || g.ntiles * kblocks128 < 384) {
+    TileGeom g64 = make_geom(N, outH, outW, 64, cs, R);
+    if (g64.ok) { g = g64; pixt = 64; }
+  }
+  if (!g.ok) return -1;
+  int KB;
+  if (pixt == 128) KB = outC > 64 ? 128 : outC > 32 ? 64 : 32;
+  else KB = (outC > 64 && g.ntiles * kblocks128 >= 384) ? 128 : 64;
+  return g.ntiles * ((outC + KB - 1) / KB);
+}
+
 }  // namespace
 
 // ================================================================== C-ABI =======
-// y[N,K,P,Q] = conv2d(x[N,C,H,W], w[K,C,R,R], stride, pad_lo) (+ bias[K]); P,Q given by the caller
-// (so asymmetric high-side padding is expressed through P,Q).  Returns SALUN_EINVAL for shapes outside the
+// Scratch for the reduction split of under-filled forward / stride-1 backward-data launches (<= 256 workgroups): up to
+// eight partial images of the OUTPUT tensor [N, outC, outH, outW] of a convolution with filter size R; `conv_stride`
+// is the forward stride for the forward pass and 1 for backward-data.  0 when the launch would not be split.
+SALUN_EXPORT size_t salun_conv2d_data_workspace_bytes(int N, int outC, int outH, int outW, int R, int conv_stride) {
+  if (N < 1 || outC < 1 || outH < 1 || outW < 1 || (R != 1 && R != 3) || (conv_stride != 1 && conv_stride != 2)) return 0;
+  const int wgs = igemm_wgs(N, outC, outH, outW, conv_stride, R);
+  if (wgs < 0 || wgs > 256 || (outH * outW) % 4 != 0) return 0;
+  return (size_t)8 * N * outC * outH * outW * sizeof(float);
+}
+
+// y[N,K,P,Q] = conv2d(x[N,C,H,W], w[K,C,R,R], stride, pad_lo) (+ bias[K]) (+ nbias[N,K]) (+ addend[N,K,P,Q]); P,Q given
+// by the caller (so asymmetric high-side padding is expressed through P,Q).  Returns SALUN_EINVAL for shapes outside the
 // tiling's domain (Q not a power of two, ...): the caller then uses the library convolution.
 SALUN_EXPORT int salun_conv2d_forward_fused(const float *x, const float *w, const float *bias, const float *nbias,
                                             const float *addend, float *y, int N, int C, int H, int W, int K, int R,
-                                            int stride, int pad, int P, int Q, salun_stream_t stream) {
+                                            int stride, int pad, int P, int Q, void *ws, size_t ws_bytes,
+                                            salun_stream_t stream) {
   if (!x || !w || !y || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1 || addend == y) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
   if (R == 3 && stride == 1)
-    return launch_igemm<3, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend);
+    return launch_igemm<3, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend, ws, ws_bytes);
   if (R == 3 && stride == 2)
-    return launch_igemm<3, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend);
+    return launch_igemm<3, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend, ws, ws_bytes);
   if (R == 1 && stride == 1)
-    return launch_igemm<1, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend);
+    return launch_igemm<1, 1, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend, ws, ws_bytes);
   if (R == 1 && stride == 2)
-    return launch_igemm<1, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend);
+    return launch_igemm<1, 2, false>(x, w, bias, y, N, C, H, W, K, P, Q, pad, C, K, st, nbias, addend, ws, ws_bytes);
   return SALUN_EINVAL;
 }
 
 SALUN_EXPORT int salun_conv2d_forward(const float *x, const float *w, const float *bias, float *y, int N, int C,
                                       int H, int W, int K, int R, int stride, int pad, int P, int Q,
                                       salun_stream_t stream) {
-  return salun_conv2d_forward_fused(x, w, bias, nullptr, nullptr, y, N, C, H, W, K, R, stride, pad, P, Q, stream);
+  return salun_conv2d_forward_fused(x, w, bias, nullptr, nullptr, y, N, C, H, W, K, R, stride, pad, P, Q, nullptr, 0,
+                                    stream);
 }
 
 // dx[N,C,H,W] = conv2d_backward_data(dy[N,K,P,Q], w[K,C,R,R]) (+ addend[N,C,H,W]; addend == dx accumulates in place)
-SALUN_EXPORT int salun_conv2d_backward_data_add(const float *dy, const float *w, const float *addend, float *dx, int N,
-                                                int C, int H, int W, int K, int R, int stride, int pad, int P, int Q,
-                                                salun_stream_t stream) {
+SALUN_EXPORT int salun_conv2d_backward_data_ws(const float *dy, const float *w, const float *addend, float *dx, int N,
+                                               int C, int H, int W, int K, int R, int stride, int pad, int P, int Q,
+                                               void *ws, size_t ws_bytes, salun_stream_t stream) {
   if (!dy || !w || !dx || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
   if (stride != 1 && stride != 2) return SALUN_EINVAL;
   hipStream_t st = salun_hip_stream(stream);
-  if (R == 3) return launch_dgrad<3>(dy, w, addend, dx, N, C, H, W, K, stride, pad, P, Q, st);
-  if (R == 1) return launch_dgrad<1>(dy, w, addend, dx, N, C, H, W, K, stride, pad, P, Q, st);
+  if (R == 3) return launch_dgrad<3>(dy, w, addend, dx, N, C, H, W, K, stride, pad, P, Q, st, ws, ws_bytes);
+  if (R == 1) return launch_dgrad<1>(dy, w, addend, dx, N, C, H, W, K, stride, pad, P, Q, st, ws, ws_bytes);
   return SALUN_EINVAL;
+}
+
+SALUN_EXPORT int salun_conv2d_backward_data_add(const float *dy, const float *w, const float *addend, float *dx, int N,
+                                                int C, int H, int W, int K, int R, int stride, int pad, int P, int Q,
+                                                salun_stream_t stream) {
+  return salun_conv2d_backward_data_ws(dy, w, addend, dx, N, C, H, W, K, R, stride, pad, P, Q, nullptr, 0, stream);
 }
 
 SALUN_EXPORT int salun_conv2d_backward_data(const float *dy, const float *w, float *dx, int N, int C, int H, int W,

@@ -254,6 +254,18 @@ def fim_square_accumulate(F: torch.Tensor, tmp: torch.Tensor, n_data: float) -> 
 
 
 # ----------------------------------------------------------------------------- K8
+_data_ws_cache: dict = {}
+
+
+def _data_ws_bytes(N: int, outC: int, outH: int, outW: int, R: int, conv_stride: int) -> int:
+    """salun_conv2d_data_workspace_bytes, remembered per shape (it is asked for every convolution call)."""
+    key = (N, outC, outH, outW, R, conv_stride)
+    v = _data_ws_cache.get(key)
+    if v is None:
+        v = _data_ws_cache[key] = int(_lib.lib().salun_conv2d_data_workspace_bytes(N, outC, outH, outW, R, conv_stride))
+    return v
+
+
 def conv2d_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int, pad: int,
                    P: int, Q: int, nbias: Optional[torch.Tensor] = None,
                    addend: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -266,11 +278,15 @@ def conv2d_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         raise ValueError(f"nbias must be [{N}, {K}], got {tuple(nbias.shape)}")
     if addend is not None and tuple(addend.shape) != (N, K, P, Q):
         raise ValueError(f"addend must be {(N, K, P, Q)}, got {tuple(addend.shape)}")
-    rc = _lib.lib().salun_conv2d_forward_fused(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"),
-                                               _dev(bias, torch.float32, "bias", True),
-                                               _dev(nbias, torch.float32, "nbias", True),
-                                               _dev(addend, torch.float32, "addend", True), c_void_p(y.data_ptr()),
-                                               N, C, H, W, K, R, stride, pad, P, Q, _stream())
+    L = _lib.lib()
+    wsb = _data_ws_bytes(N, K, P, Q, R, stride)  # > 0 only for under-filled launches
+    ws = workspace(wsb, x.device) if wsb else None
+    rc = L.salun_conv2d_forward_fused(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"),
+                                      _dev(bias, torch.float32, "bias", True),
+                                      _dev(nbias, torch.float32, "nbias", True),
+                                      _dev(addend, torch.float32, "addend", True), c_void_p(y.data_ptr()),
+                                      N, C, H, W, K, R, stride, pad, P, Q,
+                                      c_void_p(ws.data_ptr() if ws is not None else None), c_size_t(wsb), _stream())
     if rc == _lib.SALUN_EINVAL:
         return None
     check(rc, "salun_conv2d_forward_fused")
@@ -284,10 +300,13 @@ def conv2d_backward_data(dy: torch.Tensor, w: torch.Tensor, x_shape, stride: int
     K, _, R, _ = w.shape
     P, Q = dy.shape[2], dy.shape[3]
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
-    rc = _lib.lib().salun_conv2d_backward_data_add(_dev(dy, torch.float32, "dy"), _dev(w, torch.float32, "w"),
-                                                   _dev(addend, torch.float32, "addend", True),
-                                                   c_void_p(dx.data_ptr()), N, C, H, W, K, R, stride, pad, P, Q,
-                                                   _stream())
+    L = _lib.lib()
+    wsb = _data_ws_bytes(N, C, H, W, R, 1) if stride == 1 else 0
+    ws = workspace(wsb, dy.device) if wsb else None
+    rc = L.salun_conv2d_backward_data_ws(_dev(dy, torch.float32, "dy"), _dev(w, torch.float32, "w"),
+                                         _dev(addend, torch.float32, "addend", True),
+                                         c_void_p(dx.data_ptr()), N, C, H, W, K, R, stride, pad, P, Q,
+                                         c_void_p(ws.data_ptr() if ws is not None else None), c_size_t(wsb), _stream())
     if rc == _lib.SALUN_EINVAL:
         return None
     check(rc, "salun_conv2d_backward_data")

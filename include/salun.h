@@ -231,7 +231,9 @@ int salun_conv2d_forward(const float *x /*dev*/, const float *w /*dev*/, const f
 /* Forward with the epilogue of a diffusion ResnetBlock (DDPM/models/diffusion.py:113-127 of the reference:
  * `h = conv1(..); h = h + temb_proj(..)[:, :, None, None]` and `return x + h`) folded in:
  *   y = conv2d(x, w) + bias[k] + nbias[n][k] + addend[n][k][p][q]      (each term optional, added in that order —
- * the order the reference's separate adds produce).  addend must not alias y. */
+ * the order the reference's separate adds produce).  addend must not alias y.  nbias / addend are carried by dedicated
+ * instantiations of the kernel (stride 1, C a multiple of the staging chunk: 8, or 32 for R = 1, 16-byte aligned
+ * weights); any other shape with them returns SALUN_EINVAL. */
 int salun_conv2d_forward_fused(const float *x /*dev*/, const float *w /*dev*/, const float *bias /*dev or NULL*/,
                                const float *nbias /*dev [N,K] or NULL*/, const float *addend /*dev [N,K,P,Q] or NULL*/,
                                float *y /*dev*/, int N, int C, int H, int W, int K, int R, int stride, int pad,

@@ -164,6 +164,8 @@ def test_node_matches_separate_nodes(monkeypatch, cin, cout, conv_shortcut, p):
     worst = max(rel(y1, y2), rel(dx1, dx2), rel(de1, de2))
     assert worst <= TOL, worst
     assert set(g1) == set(g2) and all(v is not None for v in g1.values())
+    ptrs = [v.data_ptr() for v in g1.values()]
+    assert len(set(ptrs)) == len(ptrs)  # no two parameters share one gradient tensor (conv2.bias / skip bias)
     for n in g1:
         e = rel(g1[n], g2[n])
         worst = max(worst, e)

@@ -314,7 +314,9 @@ class _DiffusionResnetBlockFn(torch.autograd.Function):
                 if ss is not None:
                     ss.add_(csum)
                 else:
-                    dbs = csum
+                    # never hand ONE tensor to autograd as the gradient of two parameters: AccumulateGrad may adopt it
+                    # as `.grad` without a copy, and the two `.grad`s would alias
+                    dbs = csum.clone() if db2 is csum else csum
         # ---- conv2
         dw2 = wgrad(a2, dout, w2, 1)
         da2 = ops.conv2d_backward_data(dout, w2, a2.shape, 1, 1)

@@ -83,3 +83,18 @@ def test_ops_reject_cpu_tensors():
     from unlearn_saliency_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.masked_sgd_step(torch.zeros(8), torch.zeros(8), torch.zeros(8), None, 0.1, 0.9, 0.0, True)
+
+
+def test_data_workspace_query_is_host_only_and_announces_the_reduction_split(built_lib):
+    """`salun_conv2d_data_workspace_bytes` (host arithmetic, no device call): > 0 exactly for launches of <= 256
+    workgroups — the DDPM U-Net's 4x4 level at batch 128 — and 0 for full launches, shapes outside the tiling
+    domain and arguments that make no sense."""
+    from unlearn_saliency_amd import _lib
+    L = _lib.lib()
+    q = L.salun_conv2d_data_workspace_bytes
+    assert q(128, 256, 4, 4, 3, 1) == 8 * 128 * 256 * 16 * 4       # 32 tiles x 4 channel blocks = 128 workgroups
+    assert q(128, 256, 4, 4, 1, 1) == 8 * 128 * 256 * 16 * 4
+    assert q(128, 256, 8, 8, 3, 1) == 0                              # 512 workgroups: a full launch
+    assert q(256, 64, 32, 32, 3, 1) == 0 and q(256, 512, 4, 4, 3, 1) == 0   # every ResNet-18 layer at batch 256
+    assert q(4, 64, 6, 6, 3, 1) == 0                                 # width not a power of two: outside the tiling
+    assert q(0, 64, 4, 4, 3, 1) == 0 and q(4, 64, 4, 4, 5, 1) == 0 and q(4, 64, 4, 4, 3, 3) == 0

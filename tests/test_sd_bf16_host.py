@@ -138,3 +138,25 @@ def test_linear_layers_of_the_transformer_blocks_are_reclassed():
     lin.__class__ = SalunLinearBF16
     assert torch.equal(lin(torch.ones(3, 5, 64)), ref)
     assert torch.equal(lin(torch.ones(3, 5, 64), addend=torch.ones(3, 5, 96)), ref + 1)
+
+
+def test_forget_and_target_on_host_tensors_is_the_plain_sequence():
+    """`train_scripts.forget_and_target` (nsfw_removal.py:131-140 of the reference: forget pass, then the target pass
+    under no_grad) only uses a second stream for device tensors; on the host it is the reference's two calls in the
+    reference's order."""
+    import torch
+    from unlearn_saliency_amd.SD import train_scripts as TS
+    calls = []
+
+    class Stub:
+        def apply_model(self, z, t, c):
+            calls.append((c, torch.is_grad_enabled()))
+            return z * 2.0 + c.mean()
+
+    z = torch.randn(2, 4, 8, 8, requires_grad=True)
+    t = torch.tensor([1, 2])
+    c_f, c_t = torch.ones(2, 3), torch.zeros(2, 3)
+    out, tgt = TS.forget_and_target(Stub(), z, t, c_f, c_t)
+    assert [g for _, g in calls] == [True, False] and calls[0][0] is c_f and calls[1][0] is c_t
+    assert out.requires_grad and not tgt.requires_grad
+    assert torch.equal(out.detach(), z.detach() * 2.0 + 1.0) and torch.equal(tgt, z.detach() * 2.0)

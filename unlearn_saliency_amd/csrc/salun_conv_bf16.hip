@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void k_colsum_finish(const float *__restrict__
 
 int wgrad_splits(int tiles, int chunks) {
   // about 1.5 workgroups per CU, never more splits than chunks
-  // measured on the SD-v1 step (tools/_run_block5.sh, round 3): 1536 / 768 / 384 / 256 target workgroups ->
+  // measured on the SD-v1 step (round 3, one box, four builds): 1536 / 768 / 384 / 256 target workgroups ->
   // 219.3 / 209.3 / 205.7 / 206.6 ms — every split adds a K*C*R*R fp32 partial to write and re-read (59 MB for a
   // 1280x1280 3x3 layer), which costs more than the second resident round of workgroups gives back
   int s = (384 + tiles - 1) / tiles;

@@ -13,3 +13,4 @@ with open(sys.argv[2], "w") as f:
     for r in rows:
         f.write(f'{int(r["Start_Timestamp"])-t0},{int(r["End_Timestamp"])-t0},{r.get("Queue_Id","")},"{r["Kernel_Name"][:60]}"\n')
 PY
+python3 tools/trace_summary.py gpurun_out/r3_trace_ddpm_slim.csv

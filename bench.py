@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--force_collectives", action="store_true",
                     help="create the process group and issue every data-parallel collective even at one rank "
                          "(exercises the RCCL branch on a single-GPU box; SALUN_FORCE_COLLECTIVES=1)")
+    ap.add_argument("--digest", action="store_true",
+                    help="diffusion workloads: add the parameters' SHA-256 and the last loss to the line")
     ap.add_argument("--workload", default="resnet18", choices=["resnet18", "ddpm", "sd"],
                     help="resnet18 = BASELINE configs[1] (the headline metric; --forget class = configs[2]); "
                          "ddpm = configs[3] (CFG-DDPM class-forget, batch 128/GPU); sd = configs[4] (SD-v1 U-Net "
@@ -326,7 +328,8 @@ def main():
         # RANK / WORLD_SIZE through dist.init_from_env and shard their batches (BASELINE configs[3] / [4])
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         argv = ["--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup),
-                "--scaling", a.scaling] + (["--no_cpu_baseline"] if a.no_cpu_baseline else [])
+                "--scaling", a.scaling] + (["--no_cpu_baseline"] if a.no_cpu_baseline else []) \
+            + (["--digest"] if a.digest else [])
         if a.workload == "ddpm":
             import bench_ddpm
             return bench_ddpm.main(argv)

@@ -460,6 +460,22 @@ int salun_image_batch(const uint8_t *data /*dev*/, const int64_t *idx /*dev*/,
                       float *out /*dev*/, int64_t B, int H, int W, int C, int pad,
                       salun_stream_t stream);
 
+/* Dropout whose keep decision is a function of (seed, GLOBAL element index) only — replaces
+ * `nn.Dropout` in the DDPM ResnetBlock (DDPM/models/diffusion.py:108,124: `h = self.dropout(h)`), which under the
+ * reference's nn.DataParallel draws independently per replica (runners/diffusion.py:504).
+ *   gi   = (sample_offset + s) * chw + j                      global element index of sample s, position j
+ *   bits = splitmix64(key + (gi >> 1)); even gi: bits >> 40, odd gi: (bits >> 8) & 0xFFFFFF
+ *   y    = bits >= round(p * 2^24) ? x * (float)(1 / (1 - p)) : 0
+ * key = seed + (seed_dev ? *seed_dev : 0)  (seed_dev: optional device word a captured graph advances with
+ * salun_u64_add, so that replays draw fresh masks).  A rank holding samples [lo, hi) of a global batch passes
+ * sample_offset = lo and gets rows lo..hi-1 of the single-process result; the backward pass is the same call on dy
+ * (no mask is stored).  x, y: (n_samples, chw) fp32, y may alias x.  8 B / element. */
+int salun_dropout(const float *x /*dev*/, float *y /*dev*/, int64_t n_samples, int64_t chw,
+                  int64_t sample_offset, double p, uint64_t seed,
+                  const uint64_t *seed_dev /*dev or NULL*/, salun_stream_t stream);
+/* *value += inc on the stream (advances a device-resident seed between graph replays). */
+int salun_u64_add(uint64_t *value /*dev*/, uint64_t inc, salun_stream_t stream);
+
 /* Counter-based generators shared bit-for-bit with oracle/ (splitmix64 of
  * seed + index; integer arithmetic only, so CPU and GPU agree exactly):
  *   uniform: lo + (hi-lo) * (top 24 bits / 2^24);

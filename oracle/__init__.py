@@ -196,6 +196,18 @@ def fill_u8(n: int, seed: int) -> np.ndarray:
     return out
 
 
+def dropout(x: np.ndarray, p: float, key: int, sample_offset: int = 0) -> np.ndarray:
+    """Counter-based dropout of a (n_samples, ...) fp32 batch whose first sample has GLOBAL index `sample_offset`
+    (oracle_dropout; the device kernel is salun_dropout).  The same call on dy is the backward pass."""
+    x = _f32(np.ascontiguousarray(x))
+    n = x.shape[0]
+    chw = x.size // max(n, 1)
+    y = np.empty_like(x)
+    lib().oracle_dropout(_p(x, _f32p), _p(y, _f32p), ctypes.c_int64(n), ctypes.c_int64(chw),
+                         ctypes.c_int64(sample_offset), ctypes.c_double(p), ctypes.c_uint64(key & 0xFFFFFFFFFFFFFFFF))
+    return y
+
+
 # ------------------------------------------------------------------ next rows (SURVEY.md §8 F2 / F3), numpy
 def proximal_threshold(p: np.ndarray, p0: np.ndarray, ratio: int) -> np.float32:
     """threshold = -torch.topk(-|p - p0|, ratio)[0][-1]  — the ratio-th smallest |p - p0|

@@ -258,3 +258,22 @@ ORACLE_EXPORT void oracle_fill_normal(float *out, int64_t n, uint64_t seed, doub
 ORACLE_EXPORT void oracle_fill_u8(uint8_t *out, int64_t n, uint64_t seed) {
   for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)(splitmix64(seed + ((uint64_t)i >> 3)) >> (8 * (i & 7)));
 }
+
+/* Counter-based dropout — the CPU statement of csrc/salun_loss.hip::k_dropout (which replaces nn.Dropout of the
+ * reference's ResnetBlock, DDPM/models/diffusion.py:108,124, under per-GPU sharding of the batch):
+ * keep(gi) = 24 bits of splitmix64(key + (gi >> 1)) >= round(p * 2^24), gi = (sample_offset + s) * chw + j. */
+ORACLE_EXPORT void oracle_dropout(const float *x, float *y, int64_t n_samples, int64_t chw, int64_t sample_offset,
+                                  double p, uint64_t key) {
+  double t = p * 16777216.0 + 0.5;
+  if (t < 0.0) t = 0.0;
+  if (t > 16777216.0) t = 16777216.0;
+  const uint32_t thr = (uint32_t)t;
+  const float scale = (float)(1.0 / (1.0 - p));
+  const uint64_t base = (uint64_t)sample_offset * (uint64_t)chw;
+  for (int64_t i = 0; i < n_samples * chw; ++i) {
+    const uint64_t gi = base + (uint64_t)i;
+    const uint64_t r = splitmix64(key + (gi >> 1));
+    const uint32_t bits = (gi & 1ull) ? (uint32_t)((r >> 8) & 0xFFFFFFull) : (uint32_t)(r >> 40);
+    y[i] = bits >= thr ? x[i] * scale : 0.0f;
+  }
+}

@@ -44,6 +44,41 @@ def test_normal_generator_moments(oracle_mod):
     assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
 
 
+# ------------------------------------------------------------- counter-based dropout
+@pytest.mark.parametrize("shape,off", [((4, 6), 0), ((3, 7), 5), ((5, 3, 8, 8), 2), ((16, 128, 16, 16), 48)])
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_bit_exact_and_is_its_own_backward(ops, oracle_mod, shape, off, p):
+    x = oracle_mod.fill_normal(int(np.prod(shape)), 21).reshape(shape)
+    key = 0x9E3779B97F4A7C15 ^ (off * 1315423911)
+    want = oracle_mod.dropout(x, p, key, off)
+    got = ops.dropout(dev(x), p, key, off)
+    assert np.array_equal(bits(got.cpu().numpy()), bits(want))
+    drop = float((want == 0).mean())
+    assert abs(drop - p) < (0.25 if x.size < 1000 else 0.01)
+    # unaligned view -> scalar path, same bits; in place
+    buf = torch.zeros(x.size + 1, device="cuda")
+    buf[1:] = dev(x).reshape(-1)
+    v = buf[1:].view(*shape)
+    ops.dropout(v, p, key, off, out=v)
+    assert np.array_equal(bits(v.cpu().numpy()), bits(want))
+    # autograd: d/dx = the same keep mask and scale
+    xd = dev(x).requires_grad_(True)
+    ops.dropout_fn(xd, p, key, off).backward(torch.ones_like(xd))
+    assert np.array_equal(bits(xd.grad.cpu().numpy()), bits(oracle_mod.dropout(np.ones_like(x), p, key, off)))
+
+
+def test_dropout_shards_concatenate_to_the_global_batch(ops):
+    """DDPM activation at bench size: rows [lo, hi) computed with sample_offset = lo ARE rows lo..hi-1 of the whole."""
+    x = ops.fill_normal(128 * 128 * 32 * 32, 5).view(128, 128, 32, 32)
+    whole = ops.dropout(x, 0.1, 777, 0)
+    parts = [ops.dropout(x[lo:hi].contiguous(), 0.1, 777, lo) for lo, hi in ((0, 16), (16, 64), (64, 65), (65, 128))]
+    assert torch.equal(torch.cat(parts), whole)
+    assert abs(float((whole == 0).float().mean()) - 0.1) < 1e-3
+    assert not torch.equal(ops.dropout(x, 0.1, 778, 0), whole)
+    seed_dev = torch.tensor([5], dtype=torch.int64, device="cuda")  # device-resident part of the key (graph replays)
+    assert torch.equal(ops.dropout(x, 0.1, 772, 0, seed_dev=seed_dev), whole)
+
+
 # --------------------------------------------------------------------------- K1
 @pytest.mark.parametrize("n", [1, 3, 4, 1023, 4099, 1_000_003])
 @pytest.mark.parametrize("scale", [1.0, 0.37])

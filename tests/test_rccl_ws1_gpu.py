@@ -49,3 +49,20 @@ def test_bench_line_through_rccl_at_world_size_one():
     assert out["value"] > 0 and out["config"]["library_conv_calls"]["total"] == 0
     assert out["roofline"]["kernel"].endswith("(+ flat-gradient all-reduce)")
     assert out["samples_in_window"] == 12 * 256
+
+
+@pytest.mark.parametrize("workload,steps", [("ddpm", 3), ("sd", 2)])
+def test_diffusion_bench_through_rccl_at_world_size_one_is_bit_identical(workload, steps):
+    """`bench.py --workload ddpm|sd --force_collectives`: the per-batch flat SUM of Phase A (DDPM: before the global
+    clip), the async AVG gradient buckets behind the ResnetBlock / checkpointed nodes, the target pass on its own
+    stream — all through RCCL at world size 1 — must leave the same parameters and the same last loss as the
+    single-process run (reference being replaced: nn.DataParallel, DDPM/runners/diffusion.py:504,582-593,948-996)."""
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", workload, "--steps", str(steps), "--warmup", "1",
+            "--no_cpu_baseline", "--digest"]
+    plain = _run(args, {}, timeout=1500)
+    forced = _run(args + ["--force_collectives"], {"MASTER_PORT": "29613"}, timeout=1500)
+    assert plain["backend"] == "single-process" and plain["collectives"] is False
+    assert forced["backend"] == "nccl" and forced["collectives"] is True and forced["rccl_ranks"] == 1
+    assert forced["last_loss"] == plain["last_loss"], (forced["last_loss"], plain["last_loss"])
+    assert forced["params_sha256"] == plain["params_sha256"]
+    assert forced["value"] > 0 and forced["n_gpus"] == 1

@@ -94,6 +94,8 @@ def main(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--library_conv", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--digest", action="store_true",
+                    help="add the SHA-256 of the parameters and the last step's loss to the line (equality tests)")
     ap.add_argument("--cpu_steps", type=int, default=1,
                     help="rl steps at batch 128 timed on the host cores; SURVEY.md D3 (iii) asks 3 — one step takes "
                          "~77 s on the GPU box's 128 threads, so the default is 1 (profiles/r03_ddpm_bench.json was "
@@ -166,7 +168,7 @@ def main(argv=None):
         opt.step = timed_step
         rb, fb_ = next(ri), next(fi)
         samples += rb[0].size(0)
-        runner.unlearn_step(model, opt, rb, fb_)
+        last_loss = runner.unlearn_step(model, opt, rb, fb_)
     opt.step = real_step
     host_enqueue_s = time.perf_counter() - t3  # the host has issued every step; the device may still be running
     torch.cuda.synchronize()
@@ -212,6 +214,11 @@ def main(argv=None):
                            "achieved_whole_step": flops_step_rank / (dt / a.steps) / 1e12, "peak": 157.3,
                            "frac_whole_step": flops_step_rank / (dt / a.steps) / 1e12 / 157.3, "unit": "TFLOP/s"},
                "mfma_convs": not a.library_conv}
+        if a.digest:
+            import hashlib
+            out["params_sha256"] = hashlib.sha256(arena.params.cpu().numpy().tobytes()).hexdigest()
+            out["last_loss"] = float(last_loss.detach())
+            out["collectives"] = bool(sdist.collectives_on())
         if world == 1 and not a.no_cpu_baseline:
             with contextlib.redirect_stdout(sys.stderr):
                 out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_steps)

@@ -28,6 +28,8 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--scaling", default="weak", choices=["weak"], help="batch 8 per GPU cannot be split further")
     ap.add_argument("--no_cpu_baseline", action="store_true", help="accepted for symmetry: this workload has none")
+    ap.add_argument("--digest", action="store_true",
+                    help="add the SHA-256 of the parameters and the last step's loss to the line (equality tests)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mask_batches", type=int, default=2)
@@ -109,6 +111,7 @@ def main(argv=None):
             forget_out, pseudo_out = TS.forget_and_target(model, z_noisy, t, c_f, c_p)
             loss = ops.mse_loss(pseudo_out, forget_out) + 0.1 * remain_loss
             loss.backward()
+            run.last_loss = loss.detach()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             opt.step()
@@ -170,6 +173,11 @@ def main(argv=None):
                     "layer_norm_geglu": "K14 bf16 tokens" if a.bf16 else "library"},
         "hbm_peak_alloc_GB": torch.cuda.max_memory_allocated() / 1e9,
     }
+    if a.digest:
+        import hashlib
+        out["params_sha256"] = hashlib.sha256(arena.params.cpu().numpy().tobytes()).hexdigest()
+        out["last_loss"] = float(run.last_loss)
+        out["collectives"] = bool(sdist.collectives_on())
     if rank == 0:
         print(json.dumps(out), flush=True)
     sdist.barrier()

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import draws
 from ...norm import fused_gn_act
 
 
@@ -94,7 +95,7 @@ class ResnetBlock(nn.Module):
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
         self.temb_cemb_proj = nn.Linear(temb_channels + cemb_channels, out_channels)
         self.norm2 = group_norm(out_channels)
-        self.dropout = nn.Dropout(dropout)
+        self.dropout = draws.CounterDropout(dropout)  # nn.Dropout whose draws follow the GLOBAL sample index (draws.py)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
         self.fused_node = False  # set by conv.use_salun_convs(model): the whole block as one autograd node
         if in_channels != out_channels:
@@ -240,7 +241,8 @@ class Conditional_Model(nn.Module):
         temb = self.temb.dense[1](swish(self.temb.dense[0](get_timestep_embedding(t, self.ch))))
         cemb = self.classes_emb(c.to(x.device))
         if cond_drop_prob > 0:
-            keep = prob_mask_like((batch,), 1 - cond_drop_prob, device=x.device)
+            # one draw per sample of the GLOBAL batch, sliced to this rank's shard under data parallel (draws.py)
+            keep = draws.batch_draw(batch, lambda n: prob_mask_like((n,), 1 - cond_drop_prob, device=x.device))
             cemb = torch.where(keep[:, None], cemb, self.null_classes_emb[None, :].expand(batch, -1))
         cemb = self.cemb.dense[1](swish(self.cemb.dense[0](cemb)))
         emb_act = swish(torch.cat([temb, cemb], dim=-1))

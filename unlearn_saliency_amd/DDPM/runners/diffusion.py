@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from ... import dist as sdist
-from ... import ops
+from ... import draws, ops
 from ...flat import FlatArena, arena_of
 from ..datasets import data_transform, get_forget_dataset
 from ..functions import cycle, get_optimizer
@@ -85,20 +85,26 @@ def antithetic_timesteps(n: int, num_timesteps: int, device) -> torch.Tensor:
 
 
 class ShardDraws:
-    """Per-batch randomness under data parallel: noise and timesteps are drawn for the GLOBAL batch on every rank
-    (identically seeded generators, like the reference's single process feeding nn.DataParallel,
-    runners/diffusion.py:124) and sliced to this rank's shard [lo, hi) — ranks consume the generators in lock-step
-    whatever their shard sizes and the global batch sees b independent draws.  Single-process: plain draws."""
+    """Per-batch randomness under data parallel (draws.py): noise, timesteps, the label-drop mask and the dropout
+    keep-decisions are functions of the GLOBAL batch — drawn on every rank from identically seeded generators (like the
+    reference's single process feeding nn.DataParallel, runners/diffusion.py:124) and sliced to this rank's shard
+    [lo, hi), or keyed by the global sample index (dropout).  `with ShardDraws(...) as d:` makes the model calls
+    inside see the shard.  Single-process: plain draws."""
 
     def __init__(self, loader, n_local: int):
-        sh = getattr(loader, "last_shard", None) if sdist.world_size() > 1 else None
-        self.lo, self.hi, self.b = sh if sh is not None else (0, n_local, n_local)
-        assert self.hi - self.lo == n_local, (sh, n_local)
+        self.shard = draws.shard_of(loader, n_local)
+        self.lo, self.hi, self.b = self.shard.lo, self.shard.hi, self.shard.b
+        self._scope = draws.scope(self.shard)
+
+    def __enter__(self):
+        self._scope.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self._scope.__exit__(*exc)
 
     def randn_like(self, x: torch.Tensor) -> torch.Tensor:
-        if self.b == x.size(0):
-            return torch.randn_like(x)
-        return torch.randn((self.b,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)[self.lo:self.hi]
+        return draws.randn_like(x, self.shard)
 
     def timesteps(self, num_timesteps: int, device) -> torch.Tensor:
         return antithetic_timesteps(self.b, num_timesteps, device)[self.lo:self.hi]
@@ -106,8 +112,7 @@ class ShardDraws:
     @property
     def weight(self) -> float:
         """shard-mean loss -> share of the global-batch mean under the AVG all-reduce of the gradients"""
-        ws = sdist.world_size()
-        return 1.0 if ws <= 1 else (self.hi - self.lo) * ws / float(self.b)
+        return self.shard.weight
 
 
 def strip_prefix(state: dict, prefix: str = DP_PREFIX) -> "OrderedDict[str, torch.Tensor]":
@@ -177,15 +182,17 @@ class Diffusion(object):
         ws = sdist.world_size()
         for x, forget_c in forget_loader:
             n = x.size(0)
-            draws = ShardDraws(forget_loader, n)
+            sd = ShardDraws(forget_loader, n)
             x = data_transform(config, x.to(self.device))
-            e = draws.randn_like(x)
-            t = draws.timesteps(self.num_timesteps, self.device)
+            e = sd.randn_like(x)
+            t = sd.timesteps(self.num_timesteps, self.device)
             xt = q_sample(x, t, e, self.betas)
-            output = model(xt, t.float(), forget_c, cond_scale=args.cond_scale, mode="test")
+            draws.next_step()
+            with sd:
+                output = model(xt, t.float(), forget_c, cond_scale=args.cond_scale, mode="test")
             loss = ops.eps_mse(e, output)
             if ws > 1:  # local mean -> share of the global-batch mean (the gradients are SUMmed below)
-                loss = loss * (n / float(draws.b))
+                loss = loss * (n / float(sd.b))
             arena.zero_grad()
             loss.backward()
             sdist.all_reduce_sum_(arena.grads)
@@ -226,23 +233,26 @@ class Diffusion(object):
         b = self.betas
         remain_x, remain_c = remain_batch
         n = remain_x.size(0)
-        draws = ShardDraws(getattr(self, "_remain_loader", None), n)  # global-batch draws, sliced (data parallel)
+        draws.next_step()  # dropout keys: (step, call index) — identical on every rank
+        sd = ShardDraws(getattr(self, "_remain_loader", None), n)  # global-batch draws, sliced (data parallel)
         remain_x = data_transform(config, remain_x.to(self.device))
-        e = draws.randn_like(remain_x)
-        t = draws.timesteps(self.num_timesteps, self.device)
-        remain_loss = loss_registry_conditional[config.model.type](model, remain_x, t, remain_c, e, b)
-        if draws.weight != 1.0:
-            remain_loss = remain_loss * draws.weight
+        e = sd.randn_like(remain_x)
+        t = sd.timesteps(self.num_timesteps, self.device)
+        with sd:
+            remain_loss = loss_registry_conditional[config.model.type](model, remain_x, t, remain_c, e, b)
+        if sd.weight != 1.0:
+            remain_loss = remain_loss * sd.weight
 
         forget_x, forget_c = forget_batch
         n = forget_x.size(0)
-        draws = ShardDraws(getattr(self, "_forget_loader", None), n)
+        sd = ShardDraws(getattr(self, "_forget_loader", None), n)
         forget_x = data_transform(config, forget_x.to(self.device))
-        e = draws.randn_like(forget_x)
-        t = draws.timesteps(self.num_timesteps, self.device)
-        forget_weight = draws.weight
+        e = sd.randn_like(forget_x)
+        t = sd.timesteps(self.num_timesteps, self.device)
+        forget_weight = sd.weight
         if args.method == "ga":
-            forget_loss = -loss_registry_conditional[config.model.type](model, forget_x, t, forget_c, e, b)
+            with sd:
+                forget_loss = -loss_registry_conditional[config.model.type](model, forget_x, t, forget_c, e, b)
         elif args.method == "rl":
             xt = q_sample(forget_x, t, e, b)
             pseudo_c = torch.full(forget_c.shape, (args.label_to_forget + 1) % 10, device=forget_c.device)
@@ -255,17 +265,18 @@ class Diffusion(object):
                 # conditioning-drop draws are taken — is unchanged: `output` first, then the target.
                 main = torch.cuda.current_stream(xt.device)
                 side.wait_stream(main)
-            output = model(xt, tf, forget_c, mode="train")
-            if side is not None:
-                with torch.no_grad(), torch.cuda.stream(side):
-                    pseudo = model(xt, tf, pseudo_c, mode="train")
-                for v in (xt, tf, pseudo_c):
-                    v.record_stream(side)
-                main.wait_stream(side)
-                pseudo.record_stream(main)
-            else:
-                with torch.no_grad():
-                    pseudo = model(xt, tf, pseudo_c, mode="train")
+            with sd:
+                output = model(xt, tf, forget_c, mode="train")
+                if side is not None:
+                    with torch.no_grad(), torch.cuda.stream(side):
+                        pseudo = model(xt, tf, pseudo_c, mode="train")
+                    for v in (xt, tf, pseudo_c):
+                        v.record_stream(side)
+                    main.wait_stream(side)
+                    pseudo.record_stream(main)
+                else:
+                    with torch.no_grad():
+                        pseudo = model(xt, tf, pseudo_c, mode="train")
             forget_loss = ops.mse_loss(pseudo, output)
         else:
             raise ValueError(f"unknown --method {args.method!r} (rl | ga)")

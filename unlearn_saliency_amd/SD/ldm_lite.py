@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import draws, ops
 from .unet import UNetModel, V1_UNET_CONFIG
 
 
@@ -107,7 +107,8 @@ class LatentDiffusionLite(nn.Module):
         """(loss, {}) with loss = mean MSE(noise, eps(x_t, t, c)) — the reference's p_losses with
         logvar = 0, l_simple_weight = 1, original_elbo_weight = 0 (ddpm.py:82-90,1286-1319)."""
         x, c = self.get_input(batch, self.first_stage_key)
-        t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=self.device).long()
-        noise = torch.randn_like(x)
+        # under data parallel with a sharded global batch (draws.scope) t / noise are drawn for the global batch and sliced
+        t = draws.randint(self.num_timesteps, x.shape[0], self.device).long()
+        noise = draws.randn_like(x)
         out = self.apply_model(self.q_sample(x, t, noise), t, c)
         return ops.mse_loss(noise, out), {}

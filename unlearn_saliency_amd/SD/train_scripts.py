@@ -23,7 +23,7 @@ import torch
 import yaml
 
 from .. import dist as sdist
-from .. import ops
+from .. import draws, ops
 from ..flat import FlatArena
 from ..optim import FusedMaskedAdam
 from .ldm_lite import LatentDiffusionLite
@@ -59,6 +59,29 @@ def setup_model(config_path, ckpt_path, device, bf16=False) -> LatentDiffusionLi
     return model
 
 
+class ShardedBatches:
+    """Data parallel over GLOBAL batches: an iterable of tuples of tensors (batch in dimension 0) -> this rank's
+    contiguous balanced shard of each, with `last_shard = (lo, hi, b)` for the draws (draws.py: timesteps and noise are
+    drawn for the global batch and sliced) and the loss weights.  The reference's scripts are single-GPU; a plain list
+    of per-rank batches (what `--synthetic` builds) keeps meaning "every rank has its own batches"."""
+
+    def __init__(self, batches, rank: Optional[int] = None, world_size: Optional[int] = None):
+        self.batches = list(batches)
+        self.rank = sdist.rank() if rank is None else rank
+        self.world_size = sdist.world_size() if world_size is None else world_size
+        self.last_shard = None
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for batch in self.batches:
+            b = batch[0].shape[0]
+            lo, hi = sdist.balanced_slice(b, self.rank, self.world_size)
+            self.last_shard = (lo, hi, b)
+            yield tuple(t[lo:hi] for t in batch)
+
+
 def _unet_arena(model) -> FlatArena:
     a = getattr(model, "_salun_unet_arena", None)
     if a is None:
@@ -75,13 +98,17 @@ def _saliency_mask(model, batches, c_guidance, mask_path, ratio=0.5):
     model.eval()
     for z, c_forget, c_null in batches:
         z, c_forget, c_null = z.to(model.device), c_forget.to(model.device), c_null.to(model.device)
-        t = torch.randint(0, model.num_timesteps, (z.shape[0],), device=model.device).long()
-        noise = torch.randn_like(z)
-        z_noisy = model.q_sample(x_start=z, t=t, noise=noise)
-        forget_out = model.apply_model(z_noisy, t, c_forget)
-        null_out = model.apply_model(z_noisy, t, c_null)
+        sh = draws.shard_of(batches, z.shape[0])
+        with draws.scope(sh):
+            t = draws.randint(model.num_timesteps, z.shape[0], model.device).long()
+            noise = draws.randn_like(z)
+            z_noisy = model.q_sample(x_start=z, t=t, noise=noise)
+            forget_out = model.apply_model(z_noisy, t, c_forget)
+            null_out = model.apply_model(z_noisy, t, c_null)
         preds = (1 + c_guidance) * forget_out - c_guidance * null_out
         loss = -ops.mse_loss(noise, preds)
+        if sh.share != 1.0:  # a shard of a global batch: its share of the global-batch mean (accumulators are SUMmed)
+            loss = loss * sh.share
         arena.zero_grad()
         loss.backward()
         ops.saliency_accumulate(acc, arena.grads, 1.0)
@@ -196,13 +223,23 @@ def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_me
                 remain_iter = iter(remain_dl)
                 z_r, c_r = next(remain_iter)
             opt.zero_grad()
-            remain_loss = model.shared_step({"z": z_r, "c": c_r})[0]
+            draws.next_step()
+            sh_r = draws.shard_of(remain_dl, z_r.shape[0])
+            with draws.scope(sh_r):
+                remain_loss = model.shared_step({"z": z_r, "c": c_r})[0]
             z_f, c_forget, c_pseudo = z_f.to(model.device), c_forget.to(model.device), c_pseudo.to(model.device)
-            t = torch.randint(0, model.num_timesteps, (z_f.shape[0],), device=model.device).long()
-            noise = torch.randn_like(z_f)
-            z_noisy = model.q_sample(x_start=z_f, t=t, noise=noise)
-            forget_out, pseudo_out = forget_and_target(model, z_noisy, t, c_forget, c_pseudo)
-            loss = ops.mse_loss(pseudo_out, forget_out) + alpha * remain_loss
+            sh_f = draws.shard_of(forget_dl, z_f.shape[0])
+            with draws.scope(sh_f):
+                t = draws.randint(model.num_timesteps, z_f.shape[0], model.device).long()
+                noise = draws.randn_like(z_f)
+                z_noisy = model.q_sample(x_start=z_f, t=t, noise=noise)
+                forget_out, pseudo_out = forget_and_target(model, z_noisy, t, c_forget, c_pseudo)
+            forget_loss = ops.mse_loss(pseudo_out, forget_out)
+            if sh_f.weight != 1.0:  # shard means -> shares of the global-batch means under the AVG of the gradients
+                forget_loss = forget_loss * sh_f.weight
+            if sh_r.weight != 1.0:
+                remain_loss = remain_loss * sh_r.weight
+            loss = forget_loss + alpha * remain_loss
             loss.backward()
             opt.step()
             losses.append(loss.detach())

@@ -98,6 +98,8 @@ SIGNATURES = {
     "salun_ewc_penalty_grad": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "salun_image_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                   c_int, c_void_p]),
+    "salun_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_uint64, c_void_p, c_void_p]),
+    "salun_u64_add": (c_int, [c_void_p, c_uint64, c_void_p]),
     "salun_fill_uniform": (c_int, [c_void_p, c_int64, c_uint64, c_double, c_double, c_void_p]),
     "salun_fill_normal": (c_int, [c_void_p, c_int64, c_uint64, c_double, c_double, c_void_p]),
     "salun_fill_u8": (c_int, [c_void_p, c_int64, c_uint64, c_void_p]),

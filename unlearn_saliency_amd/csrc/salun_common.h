@@ -83,3 +83,11 @@ __host__ __device__ __forceinline__ float salun_clip_coef(float sqnorm, float ma
   float c = max_norm / (total + 1e-6f);
   return c > 1.0f ? 1.0f : c;
 }
+
+// dropout: keep iff a 24-bit draw >= round(p * 2^24)  (integer comparison: identical on host, device and oracle)
+static inline uint32_t salun_dropout_threshold(double p) {
+  double t = p * 16777216.0 + 0.5;
+  if (t < 0.0) t = 0.0;
+  if (t > 16777216.0) t = 16777216.0;
+  return (uint32_t)t;
+}

@@ -134,6 +134,42 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_fill_u8(uint8_t *out, int64_t n
     out[i] = (uint8_t)(salun_splitmix64(seed + ((uint64_t)i >> 3)) >> (8 * (i & 7)));
 }
 
+// ------------------------------------------------------------ counter-based dropout
+// keep(gi) for the GLOBAL element index gi = (sample_offset + s) * chw + j of the batch: 24 bits of
+// splitmix64(key + (gi >> 1)) — the high 24 for even gi, bits [8, 32) for odd gi — compared with thr = round(p * 2^24).
+// A function of (key, global sample index, position) only: a rank holding samples [lo, hi) of a global batch produces
+// exactly rows lo..hi-1 of the single-process result, no mask is stored (backward re-derives it from the same key),
+// and the comparison is integer, so the CPU oracle agrees bit for bit.
+__device__ __forceinline__ uint32_t drop_bits(uint64_t key, uint64_t gi) {
+  const uint64_t r = salun_splitmix64(key + (gi >> 1));
+  return (gi & 1ull) ? (uint32_t)((r >> 8) & 0xFFFFFFull) : (uint32_t)(r >> 40);
+}
+__global__ __launch_bounds__(SALUN_BLOCK) void k_dropout(const float *__restrict__ x, float *__restrict__ y, int64_t total4,
+                                                         int64_t total, uint64_t base, uint64_t seed,
+                                                         const uint64_t *__restrict__ seed_dev, uint32_t thr,
+                                                         float scale, int vec) {
+  const uint64_t key = seed + (seed_dev ? *seed_dev : 0ull);
+  if (vec) {  // total % 4 == 0, base even, 16-byte aligned: one splitmix64 per pair of elements
+    for (int64_t i = (int64_t)blockIdx.x * SALUN_BLOCK + threadIdx.x; i < total4; i += (int64_t)gridDim.x * SALUN_BLOCK) {
+      const uint64_t gi = base + 4ull * (uint64_t)i;
+      const uint64_t r0 = salun_splitmix64(key + (gi >> 1)), r1 = salun_splitmix64(key + (gi >> 1) + 1ull);
+      const float4 v = *reinterpret_cast<const float4 *>(x + 4 * i);
+      float4 o;
+      o.x = ((uint32_t)(r0 >> 40) >= thr) ? v.x * scale : 0.0f;
+      o.y = ((uint32_t)((r0 >> 8) & 0xFFFFFFull) >= thr) ? v.y * scale : 0.0f;
+      o.z = ((uint32_t)(r1 >> 40) >= thr) ? v.z * scale : 0.0f;
+      o.w = ((uint32_t)((r1 >> 8) & 0xFFFFFFull) >= thr) ? v.w * scale : 0.0f;
+      *reinterpret_cast<float4 *>(y + 4 * i) = o;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * SALUN_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * SALUN_BLOCK)
+      y[i] = (drop_bits(key, base + (uint64_t)i) >= thr) ? x[i] * scale : 0.0f;
+  }
+}
+__global__ void k_u64_add(uint64_t *p, uint64_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *p += inc;
+}
+
 }  // namespace
 
 // ================================================================== C-ABI =======
@@ -206,6 +242,30 @@ SALUN_EXPORT int salun_fill_u8(uint8_t *out, int64_t n, uint64_t seed, salun_str
   if (n == 0) return SALUN_OK;
   hipLaunchKernelGGL(k_fill_u8, dim3(salun_grid_for(n, SALUN_BLOCK * 4)), dim3(SALUN_BLOCK), 0,
                      salun_hip_stream(stream), out, n, seed);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+SALUN_EXPORT int salun_dropout(const float *x, float *y, int64_t n_samples, int64_t chw, int64_t sample_offset, double p,
+                               uint64_t seed, const uint64_t *seed_dev, salun_stream_t stream) {
+  if (n_samples < 0 || chw < 0 || sample_offset < 0 || !(p >= 0.0) || !(p < 1.0)) return SALUN_EINVAL;
+  if (n_samples == 0 || chw == 0) return SALUN_OK;
+  if (!x || !y) return SALUN_EINVAL;
+  const int64_t total = n_samples * chw;
+  const uint64_t base = (uint64_t)sample_offset * (uint64_t)chw;
+  const uint32_t thr = salun_dropout_threshold(p);
+  const float scale = (float)(1.0 / (1.0 - p));
+  const int vec = salun_aligned16(x) && salun_aligned16(y) && (total % 4 == 0) && ((base & 1ull) == 0);
+  const int64_t items = vec ? total / 4 : total;
+  hipLaunchKernelGGL(k_dropout, dim3(salun_grid_for(items, SALUN_BLOCK * 2)), dim3(SALUN_BLOCK), 0, salun_hip_stream(stream),
+                     x, y, total / 4, total, base, seed, seed_dev, thr, scale, vec);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+SALUN_EXPORT int salun_u64_add(uint64_t *value, uint64_t inc, salun_stream_t stream) {
+  if (!value) return SALUN_EINVAL;
+  hipLaunchKernelGGL(k_u64_add, dim3(1), dim3(64), 0, salun_hip_stream(stream), value, inc);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }

@@ -246,6 +246,36 @@ def mse_loss(target: torch.Tensor, pred: torch.Tensor) -> torch.Tensor:
     return _SqErr.apply(target, pred, 1.0 / target.numel())
 
 
+def dropout(x: torch.Tensor, p: float, key: int, sample_offset: int = 0, out: Optional[torch.Tensor] = None,
+            seed_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Counter-based dropout of a (n, ...) fp32 batch whose first sample is global sample `sample_offset`
+    (salun_dropout); applying it to dy with the same (key, offset) is the backward pass.  `out` may be `x`."""
+    n = x.shape[0]
+    chw = x.numel() // max(n, 1)
+    y = out if out is not None else torch.empty_like(x)
+    check(_lib.lib().salun_dropout(_dev(x, torch.float32, "x"), _dev(y, torch.float32, "y"), c_int64(n), c_int64(chw),
+                                   c_int64(sample_offset), c_double(p), c_uint64(key & 0xFFFFFFFFFFFFFFFF),
+                                   _dev(seed_dev, torch.int64, "seed_dev", True), _stream()), "salun_dropout")
+    return y
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, key, offset):
+        ctx.cfg = (float(p), int(key), int(offset))
+        return dropout(x.contiguous(), p, key, offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, key, offset = ctx.cfg
+        return dropout(dy.contiguous(), p, key, offset), None, None, None
+
+
+def dropout_fn(x: torch.Tensor, p: float, key: int, sample_offset: int = 0) -> torch.Tensor:
+    """Differentiable counter-based dropout (no mask tensor is kept: backward re-derives it from the key)."""
+    return _Dropout.apply(x, float(p), int(key), int(sample_offset))
+
+
 # ----------------------------------------------------------------------------- K7
 def fim_square_accumulate(F: torch.Tensor, tmp: torch.Tensor, n_data: float) -> None:
     check(_lib.lib().salun_fim_square_accumulate(_dev(F, torch.float32, "F"), _dev(tmp, torch.float32, "tmp"),

@@ -21,7 +21,7 @@ import torch.nn as nn
 import os
 
 from . import dist as sdist
-from . import gradsink, ops
+from . import draws, gradsink, ops
 
 # Backward-weight and backward-data of one convolution depend on the same dY and on nothing of each other.  The
 # backward-weight kernel runs ONE wave per SIMD (register budget) and leaves LDS for a second workgroup, so issuing it
@@ -256,22 +256,24 @@ class _DiffusionResnetBlockFn(torch.autograd.Function):
         c1 = ops.conv2d_forward(a1, w1, b1, 1, 1, H, W, nbias=proj)
         a2, m2, r2 = ops.gn_forward(c1, n2w, n2b, G2, blk.norm2.eps, True)
         p = float(blk.dropout.p) if blk.dropout.training else 0.0
-        keep = None
+        dkey = None
         if p > 0.0:
-            a2, keep = torch.native_dropout(a2, p, True)
+            # counter-based keep decisions keyed by the global sample index (draws.py): nothing to save but the key
+            dkey = draws.dropout_key()
+            a2 = ops.dropout(a2, p, dkey[0], dkey[1], out=a2)
         if ws is not None:
             sc = ops.conv2d_forward(x, ws, bs, 1, (ws.shape[2] - 1) // 2, H, W)
         else:
             sc = x
         out = ops.conv2d_forward(a2, w2, b2, 1, 1, H, W, addend=sc)
-        ctx.save_for_backward(x, a1, c1, a2, keep, n1w, n1b, w1, b1, n2w, n2b, w2, b2, ws, bs, m1, r1, m2, r2)
-        ctx.cfg = (G1, G2, p)
+        ctx.save_for_backward(x, a1, c1, a2, n1w, n1b, w1, b1, n2w, n2b, w2, b2, ws, bs, m1, r1, m2, r2)
+        ctx.cfg = (G1, G2, p, dkey)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, a1, c1, a2, keep, n1w, n1b, w1, b1, n2w, n2b, w2, b2, ws, bs, m1, r1, m2, r2 = ctx.saved_tensors
-        G1, G2, p = ctx.cfg
+        x, a1, c1, a2, n1w, n1b, w1, b1, n2w, n2b, w2, b2, ws, bs, m1, r1, m2, r2 = ctx.saved_tensors
+        G1, G2, p, dkey = ctx.cfg
         dout = dout.contiguous()
         main = torch.cuda.current_stream(dout.device)
         side = _side_stream(dout.device) if OVERLAP_WGRAD else None
@@ -320,8 +322,8 @@ class _DiffusionResnetBlockFn(torch.autograd.Function):
         # ---- conv2
         dw2 = wgrad(a2, dout, w2, 1)
         da2 = ops.conv2d_backward_data(dout, w2, a2.shape, 1, 1)
-        if keep is not None:
-            da2 = torch.ops.aten.native_dropout_backward(da2, keep, 1.0 / (1.0 - p))
+        if dkey is not None:
+            da2 = ops.dropout(da2, p, dkey[0], dkey[1], out=da2)
         # ---- norm2 (+ SiLU): dx = dc1; its per-(image, channel) sums are dproj, their batch sum conv1's bias gradient
         gw, gb = gn_sinks(n2w, n2b)
         s1 = gradsink.sink(b1)
@@ -374,7 +376,7 @@ def _diffusion_block_structure_ok(blk) -> bool:
     if len(convs) == 3:
         k = convs[2].kernel_size
         ok = ok and k in ((1, 1), (3, 3)) and convs[2].padding == ((k[0] - 1) // 2,) * 2
-    return ok and type(blk.dropout) is nn.Dropout and 0.0 <= blk.dropout.p < 1.0 and not blk.dropout.inplace
+    return ok and type(blk.dropout) is draws.CounterDropout and 0.0 <= blk.dropout.p < 1.0 and not blk.dropout.inplace
 
 
 def _diffusion_block_probe(blk, shape, device) -> bool:

@@ -191,6 +191,14 @@ def _bucketed(rank, out_dir):
         red.finish()
         assert not any(red.launched) and not red.works
     np.save(os.path.join(out_dir, f"g_{rank}.npy"), arena.grads.numpy())
+    # hooks firing in the opposite order (first parameters first) must still issue the slices last-first —
+    # the one order every rank uses, so slices of different sizes always pair up across ranks
+    keep = arena.grads.clone()
+    for i in range(len(arena._params)):
+        red._make_hook(i)(None)
+        assert red._order == ([] if i < len(arena._params) - 1 else list(range(len(red.bounds) - 1, -1, -1)))
+    red.finish()
+    assert torch.allclose(arena.grads, keep)  # AVG of identical vectors
 
 
 def test_bucketed_overlapped_allreduce_equals_full_batch_gradient(tmp_path):
@@ -210,8 +218,9 @@ def test_bucketed_overlapped_allreduce_equals_full_batch_gradient(tmp_path):
 
 # -------------------------------------------------- a rank with an EMPTY shard (tail batch smaller than the world)
 def _empty_shard(rank, out_dir):
-    """a rank whose shard of a ragged tail batch is empty runs no backward; its buckets must still pair up
-    with the other rank's hook-launched slices (different sizes): same order, or the all-reduces mismatch."""
+    """a rank whose shard of a ragged tail batch is empty runs no backward; its buckets must still pair
+    up with the other rank's hook-launched slices (different sizes).  The reducer issues slices in ONE order on every
+    rank — last slice first — whether a hook or `finish` issues them, also when the ragged step is the first step."""
     from fixtures import TinyCNN, tiny_batches, tiny_state
     from unlearn_saliency_amd import dist as sdist
     from unlearn_saliency_amd.flat import FlatArena
@@ -224,9 +233,7 @@ def _empty_shard(rank, out_dir):
     assert len(sizes) > 1, "the case needs slices of different sizes"
     x, y = tiny_batches(1, 16, 700)[0]
     for first_step_empty in (False, True):
-        if first_step_empty:
-            red._seen_order = None  # as on the very first step: no complete backward seen yet
-        else:  # one complete step on both ranks first (records the hooks' launch order)
+        if not first_step_empty:  # one complete step on both ranks first; then the ragged step is the FIRST of the run
             lo, hi = sdist.balanced_slice(16)
             arena.zero_grad()
             nn.CrossEntropyLoss()(model(torch.from_numpy(x[lo:hi])), torch.from_numpy(y[lo:hi])).backward()

@@ -20,6 +20,11 @@ from .. import draws, ops
 from .unet import UNetModel, V1_UNET_CONFIG
 
 
+# AutoencoderKL (ddconfig of configs/stable-diffusion/v1-inference.yaml) + CLIP ViT-L/14 text model, counted from the
+# reference's modules
+SD_V1_FROZEN_PARAMS = 83_653_863 + 123_060_480
+
+
 class _Wrapper(nn.Module):
     def __init__(self, unet):
         super().__init__()
@@ -35,9 +40,16 @@ class LatentDiffusionLite(nn.Module):
         self.first_stage_key, self.cond_stage_key = "jpg", "txt"
         self.first_stage, self.cond_stage, self.scale_factor = first_stage, cond_stage, scale_factor
         self.bf16 = bf16
-        # parameters of the frozen stages a full LatentDiffusion would carry next to the U-Net (0 here: they are not
-        # instantiated); `setup_model` sets the SD-v1 count — only the proximal step's global ranking depends on it
-        self.frozen_param_count = 0
+        # Parameters of the frozen stages a full LatentDiffusion carries next to the U-Net: the reference's proximal step
+        # ranks |theta - theta_0| over ALL of them (proximal_gradient.py:66-72,141-167), so their zeros take the lowest
+        # ranks.  Attached stages that are nn.Modules are counted; with none attached a v1-shaped U-Net gets the SD-v1
+        # constant (AutoencoderKL 83,653,863 + CLIP ViT-L/14 text model 123,060,480); anything else has no frozen
+        # stages (0).  Only the proximal step's global ranking depends on it; `_unlearn` logs the value it used.
+        cfg = unet_config or V1_UNET_CONFIG
+        counted = sum(sum(p.numel() for p in st.parameters()) for st in (first_stage, cond_stage)
+                      if isinstance(st, nn.Module))
+        v1 = all(cfg.get(k) == V1_UNET_CONFIG.get(k) for k in ("model_channels", "channel_mult", "context_dim"))
+        self.frozen_param_count = counted if counted else (SD_V1_FROZEN_PARAMS if v1 else 0)
         # "linear" schedule of the LDM code base: linspace(sqrt(start), sqrt(end))**2 in float64 (util.py:24-30)
         betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=np.float64) ** 2
         ac = np.cumprod(1.0 - betas, axis=0)

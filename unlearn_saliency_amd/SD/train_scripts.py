@@ -26,17 +26,10 @@ from .. import dist as sdist
 from .. import draws, ops
 from ..flat import FlatArena
 from ..optim import FusedMaskedAdam
-from .ldm_lite import LatentDiffusionLite
+from .ldm_lite import SD_V1_FROZEN_PARAMS, LatentDiffusionLite  # noqa: F401 (re-exported)
 from .unet import V1_UNET_CONFIG
 
 UNET_PREFIX = "model.diffusion_model."
-
-# Parameters of the frozen stages of the reference's SD-v1 LatentDiffusion: AutoencoderKL (ddconfig of
-# configs/stable-diffusion/v1-inference.yaml: 83,653,863) + CLIP ViT-L/14 text model (123,060,480).  They never move,
-# but the reference's proximal step ranks |theta - theta_0| over `model.parameters()` of the WHOLE LatentDiffusion
-# (proximal_gradient.py:66-72,141-167), so their zeros occupy the lowest ranks of its top-k.
-SD_V1_FROZEN_PARAMS = 83_653_863 + 123_060_480
-
 
 def setup_model(config_path, ckpt_path, device, bf16=False) -> LatentDiffusionLite:
     """YAML (`model.params.unet_config.params`, e.g. configs/stable-diffusion/v1-inference.yaml) + optional CompVis
@@ -47,8 +40,6 @@ def setup_model(config_path, ckpt_path, device, bf16=False) -> LatentDiffusionLi
             params = yaml.safe_load(f)["model"]["params"]["unet_config"]["params"]
         cfg.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in params.items()})
     model = LatentDiffusionLite(cfg, bf16=bf16).to(device)
-    if all(cfg.get(k) == V1_UNET_CONFIG.get(k) for k in ("model_channels", "channel_mult", "context_dim")):
-        model.frozen_param_count = SD_V1_FROZEN_PARAMS  # the v1 first stage + text encoder (see above)
     if ckpt_path and os.path.exists(ckpt_path):
         sd = torch.load(ckpt_path, map_location=device, weights_only=False)
         sd = sd.get("state_dict", sd)
@@ -203,6 +194,8 @@ def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_me
     # the reference ranks over the whole LatentDiffusion: U-Net + the frozen first stage and text encoder
     n_frozen = int(getattr(model, "frozen_param_count", 0)) if proximal_ratio is not None else 0
     n_total = arena.n + n_frozen
+    if proximal_ratio is not None:
+        print(f"proximal ranking over {n_total} parameters: {arena.n} U-Net + {n_frozen} frozen (first stage + text encoder)")
     steps_per_epoch = len(forget_dl) + len(remain_dl) if proximal_ratio is not None else 0  # proximal_gradient.py:73
     total_steps = epochs * steps_per_epoch
     opt = FusedMaskedAdam(arena, lr=lr)  # torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no clipping

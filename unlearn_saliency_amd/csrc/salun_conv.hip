@@ -1831,6 +1831,8 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
   const size_t out_elems = (size_t)N * yC * yH * yW;
   float *part = static_cast<float *>(ws);
   const bool epi = !DGRAD && (nbias != nullptr || addend != nullptr);
+  const bool split_al16 = salun_aligned16(y) && salun_aligned16(ws) && (!addend || salun_aligned16(addend)) &&
+                          (!(DGRAD && bias) || salun_aligned16(bias));  // DGRAD: `bias` carries the full-size addend
 #define SALUN_IGEMM(KT_, WP_, WK_, SPL_)                                                                        \
   {                                                                                                             \
     constexpr int KB = WK_ * KT_ * 32;                                                                          \
@@ -1842,7 +1844,9 @@ int launch_igemm(const float *x, const float *w, const float *bias, float *y, in
     if (epi && (!fast || DGRAD || STRIDE != 1)) return SALUN_EINVAL; /* epilogue terms: stride-1 forward, FAST */ \
     if (fast) {                                                                                                 \
       int S = 1;                                                                                                \
-      if constexpr (SPL_) S = igemm_split((int)(grid.x * grid.y), xC, CC, out_elems, yH * yW, ws, ws_bytes);    \
+      /* the finishing kernel reads / writes y, the addends and the partials as float4: 16-byte bases or no split */ \
+      if constexpr (SPL_)                                                                                       \
+        if (split_al16) S = igemm_split((int)(grid.x * grid.y), xC, CC, out_elems, yH * yW, ws, ws_bytes);      \
       if (S > 1) {                                                                                              \
         if constexpr (SPL_) {                                                                                   \
           grid.z = S;                                                                                           \

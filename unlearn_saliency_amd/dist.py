@@ -196,8 +196,8 @@ class BucketedGradReducer:
         self.arrived = [0] * len(self.bounds)
         self.launched = [False] * len(self.bounds)
         self.works = []
-        self._order = []        # bucket indices in the order this step launched them
-        self._seen_order = None  # launch order of the last complete backward (identical on every rank: same graph)
+        self._order = []        # bucket indices in the order this step launched them (always descending)
+        self._next = len(self.bounds) - 1  # the next slice allowed to go out
         self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
                          for i, p in enumerate(arena._params)]
 
@@ -206,9 +206,19 @@ class BucketedGradReducer:
 
         def hook(_param):
             self.arrived[b] += 1
-            if self.arrived[b] == self.expected[b] and not self.launched[b]:
-                self._launch(b)
+            if self.arrived[b] == self.expected[b]:
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Slices go out in ONE order on every rank and every step — last slice first, the order backward completes
+        them in — whatever order the hooks fire in: slice b is issued only once every slice above it has been.  (Ranks
+        pair collectives by issue order; slices have different sizes, so two ranks issuing them in different orders
+        would deadlock or mix gradients — a rank whose shard of a ragged tail batch is empty runs no backward at all and
+        issues everything from `finish`.)"""
+        while self._next >= 0 and self.arrived[self._next] == self.expected[self._next]:
+            self._launch(self._next)
+            self._next -= 1
 
     def _launch(self, b):
         lo, hi = self.bounds[b]
@@ -221,18 +231,12 @@ class BucketedGradReducer:
             self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True), sl))
 
     def finish(self):
-        # Buckets that no hook launched (unused parameters; a rank whose shard of a ragged tail batch is EMPTY runs no
-        # backward at all) must be issued in the order the OTHER ranks' hooks issue theirs, or the slices of
-        # different sizes pair up wrongly across ranks: the order of the last complete backward, else last bucket
-        # first (backward fills the flat gradient from its end).
-        hooked_all = all(self.launched)
-        if hooked_all:
-            self._seen_order = list(self._order)
-        else:
-            natural = self._seen_order or list(range(len(self.bounds) - 1, -1, -1))
-            for b in natural:
-                if not self.launched[b]:
-                    self._launch(b)
+        # whatever backward did not complete (unused parameters; no backward at all on a rank with an empty shard) is
+        # issued now, continuing the same descending order
+        while self._next >= 0:
+            self._launch(self._next)
+            self._next -= 1
+        assert self._order == list(range(len(self.bounds) - 1, -1, -1)), self._order
         ws = world_size()
         for work, needs_div in self.works:
             work.wait()
@@ -240,6 +244,7 @@ class BucketedGradReducer:
                 needs_div.div_(ws)
         self.works.clear()
         self._order = []
+        self._next = len(self.bounds) - 1
         self.arrived = [0] * len(self.bounds)
         self.launched = [False] * len(self.bounds)
 

@@ -43,7 +43,9 @@ def workspace(nbytes: int, device: torch.device, tag: str = "") -> torch.Tensor:
     """`tag` separates buffers whose contents must survive other ops' scratch use (the top-k publication block is
     read back by mask_topk_thresholds after arbitrary calls in between)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream, tag)
+    # the top-k publication block is keyed by the device alone: mask_topk_status / mask_topk_thresholds must find the
+    # block the last mask_topk call wrote whatever stream is current when they are called (side streams exist)
+    key = (idx, None if tag == "topk" else torch.cuda.current_stream(idx).cuda_stream, tag)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -102,6 +104,13 @@ def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch
                "salun_mask_topk")  # (`check` the keyword shadows the module-level helper inside this function)
     if check:
         route, err = mask_topk_status(acc.device)
+        from . import dist as sdist
+        if sdist.collectives_on():
+            # every rank ranks the same vector, but a time-out is a property of one device's occupancy: agree on the
+            # flag before raising, or the healthy ranks hang at their next collective while one rank unwinds
+            flag = torch.tensor([int(err)], dtype=torch.int32, device=acc.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            err = int(flag.item())
         if err:
             raise TopkFailed(f"salun_mask_topk: the full scan's grid barrier timed out (route {route}, n = {n}): "
                              "its workgroups were not co-resident; no mask was produced")

@@ -12,14 +12,16 @@ EXECUTES the reference's own functions, imported from /root/reference/SD/train-s
 What is stubbed is only what the image lacks and what the functions use as *plumbing*: `dataset` (its `setup_model`
 / `setup_*_data` return the objects built here), `diffusers.LMSDiscreteScheduler` (constructed, never used),
 `convertModels.savemodelDiffusers`, `ldm.models.diffusion.ddim.DDIMSampler`, `torchvision.utils.make_grid`, `sleep`.
-`LatentDiffusion` itself needs pytorch_lightning, so the model handed to the scripts is a duck-typed module around
-the REFERENCE's `UNetModel` (openaimodel.py:428-847) that implements the five members the scripts touch
-(`get_input`, `q_sample`, `apply_model`, `shared_step`, `num_timesteps` / `device` / `first_stage_key`) from
-ddpm.py:424-430, :1093-1109, :1121, :1286-1319 with the reference's own `make_beta_schedule` /
-`extract_into_tensor`.  "Images" are latents and "prompts" index a table of fixed context embeddings (the frozen VAE /
-CLIP are outside the hot-path scope); `get_input` is deterministic, so `pseudo_input == forget_input` as in this
-build's formulation.  For `proximal_gradient` the module also carries frozen stand-ins for the first stage and the
-text encoder, because the reference ranks |theta - theta_0| over `model.parameters()` of the WHOLE model.
+The model handed to the scripts is the REFERENCE's own `LatentDiffusion` (ldm/models/diffusion/ddpm.py:605-) around
+its `UNetModel` (openaimodel.py:428-847): `get_input`, `q_sample` (:424-430), `apply_model` (:1121), `shared_step` /
+`forward` / `p_losses` (:1093-1109, :1286-1319) are executed, not restated.  `pytorch_lightning` is absent from the
+image; `LightningModule` is stood in by `nn.Module` + a `device` property (round 4; rounds 2-3 used a duck-typed module
+that re-wrote those five members — the fixture did not change by a bit when the real class replaced it).  "Images" are
+latents and "prompts" index a table of fixed context embeddings: the frozen VAE / CLIP are outside the hot-path scope,
+so `first_stage_config` / `cond_stage_config` point at an identity encoder and a prompt table; `get_input` is
+deterministic, so `pseudo_input == forget_input` as in this build's formulation.  For `proximal_gradient` the two
+stages carry parameters that never move, because the reference ranks |theta - theta_0| over `model.parameters()` of
+the WHOLE model.
 
 Every `torch.randint` / `torch.randn_like` result is recorded in call order (the tests replay them), `torch.abs_` is
 observed to capture the accumulated gradients inside the mask functions, `torch.optim.Adam` to keep the optimizer.
@@ -53,62 +55,97 @@ torch.set_num_threads(8)
 STRIDE = 7  # strided samples of N-sized vectors kept in the fixture
 
 
-# ------------------------------------------------------------------ the duck-typed LatentDiffusion
-def build_ref_ldm(frozen: bool = False):
-    from ldm.modules.diffusionmodules.openaimodel import UNetModel as RefUNet
-    from ldm.modules.diffusionmodules.util import extract_into_tensor, make_beta_schedule
+# ------------------------------------------------------------------ the reference's LatentDiffusion
+def _stub_lightning_and_stages():
+    """What `ldm.models.diffusion.ddpm` imports but the image lacks: pytorch_lightning (its LightningModule is used as an
+    nn.Module with a `device` property; nothing of the Trainer is touched by the SalUn scripts) and
+    `ldm.models.autoencoder` (taming / lightning; only class NAMES are imported from it).  The frozen stages themselves
+    (AutoencoderKL, CLIP) are outside the hot-path scope: `first_stage_config` / `cond_stage_config` point at the stand-ins
+    below — an identity encoder ("images" are latents) and a prompt -> fixed-embedding table."""
+    if "pytorch_lightning" not in sys.modules or not hasattr(sys.modules["pytorch_lightning"], "LightningModule"):
+        pl = types.ModuleType("pytorch_lightning")
 
-    class DiffusionWrapper(nn.Module):  # ddpm.py: DiffusionWrapper with conditioning_key "crossattn"
-        def __init__(self, unet):
-            super().__init__()
-            self.diffusion_model = unet
+        class LightningModule(nn.Module):
+            @property
+            def device(self):
+                for t in list(self.parameters()) + list(self.buffers()):
+                    return t.device
+                return torch.device("cpu")
 
-    class DuckLDM(nn.Module):
+        pl.LightningModule = LightningModule
+        util = types.ModuleType("pytorch_lightning.utilities")
+        dist = types.ModuleType("pytorch_lightning.utilities.distributed")
+        dist.rank_zero_only = lambda fn: fn
+        util.distributed = dist
+        pl.utilities = util
+        sys.modules.update({"pytorch_lightning": pl, "pytorch_lightning.utilities": util,
+                            "pytorch_lightning.utilities.distributed": dist})
+    ae = types.ModuleType("ldm.models.autoencoder")
+    for name in ("AutoencoderKL", "IdentityFirstStage", "VQModelInterface"):
+        setattr(ae, name, type(name, (nn.Module,), {}))
+    sys.modules["ldm.models.autoencoder"] = ae
+    st = types.ModuleType("salun_golden_stages")
+
+    class LatentsAsImages(nn.Module):
+        """first stage: `encode` is the identity (the data handed to the scripts are latents)."""
+
+        def encode(self, x):
+            return x
+
+        def decode(self, z):
+            return z
+
+    class FrozenLatentsAsImages(nn.Linear):
+        """the same with 90,300 parameters that never receive a gradient (proximal_gradient ranks over them too)."""
+
+        def __init__(self):
+            super().__init__(300, 300)
+
+        def encode(self, x):
+            return x
+
+    class PromptTable(nn.Module):
+        """cond stage: prompt -> fixed (7, 24) context embedding."""
+
         def __init__(self):
             super().__init__()
-            self.model = DiffusionWrapper(fill_params(RefUNet(**sd_glue_config()), 9100))
-            if frozen:  # stand-ins for first_stage_model / cond_stage_model: parameters that never receive a gradient
-                # (140,300 next to the U-Net's 250,372 — about the proportion of SD v1: 207 M next to 860 M)
-                self.first_stage_model = nn.Linear(300, 300)
-                self.cond_stage_model = nn.Linear(200, 250, bias=False)
-                for q in list(self.first_stage_model.parameters()) + list(self.cond_stage_model.parameters()):
-                    q.requires_grad_(False)
-                fill_params(self.first_stage_model, 9200)
-                fill_params(self.cond_stage_model, 9300)
-            self.first_stage_key, self.num_timesteps = "jpg", 1000
-            betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.0120, cosine_s=8e-3)
-            ac = np.cumprod(1.0 - betas, axis=0)
-            self.register_buffer("sqrt_alphas_cumprod", torch.tensor(np.sqrt(ac), dtype=torch.float32))
-            self.register_buffer("sqrt_one_minus_alphas_cumprod", torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32))
             self.contexts = {k: torch.from_numpy(v) for k, v in sd_glue_contexts().items()}
 
-        @property
-        def device(self):
-            return self.sqrt_alphas_cumprod.device
+        def encode(self, prompts):
+            return torch.stack([self.contexts[p] for p in prompts])
 
-        def get_input(self, batch, k):
-            x = batch[k].permute(0, 3, 1, 2).contiguous().float()       # ddpm.py get_input: b h w c -> b c h w
-            c = torch.stack([self.contexts[p] for p in batch["txt"]])
-            return x, c
+    class FrozenPromptTable(PromptTable):
+        def __init__(self):
+            super().__init__()
+            self.proj = nn.Linear(200, 250, bias=False)  # 50,000 parameters that never receive a gradient
 
-        def q_sample(self, x_start, t, noise=None):                      # ddpm.py:424-430
-            return (extract_into_tensor(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
-                    + extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+    st.LatentsAsImages, st.FrozenLatentsAsImages = LatentsAsImages, FrozenLatentsAsImages
+    st.PromptTable, st.FrozenPromptTable = PromptTable, FrozenPromptTable
+    sys.modules["salun_golden_stages"] = st
 
-        def apply_model(self, x_noisy, t, cond):                         # ddpm.py:1121 -> DiffusionWrapper "crossattn"
-            return self.model.diffusion_model(x_noisy, t, context=cond)
 
-        def shared_step(self, batch):                                    # ddpm.py:1093-1109, p_losses :1286-1319
-            x, c = self.get_input(batch, self.first_stage_key)
-            t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=self.device).long()
-            noise = torch.randn_like(x)
-            model_output = self.apply_model(self.q_sample(x_start=x, t=t, noise=noise), t, c)
-            loss_simple = torch.nn.functional.mse_loss(noise, model_output, reduction="none").mean([1, 2, 3])
-            logvar_t = torch.zeros_like(loss_simple)                     # logvar_init = 0, not learned
-            loss = (loss_simple / torch.exp(logvar_t) + logvar_t).mean() * 1.0   # l_simple_weight = 1
-            return loss, {}                                              # original_elbo_weight = 0: no vlb term
-
-    return DuckLDM()
+def build_ref_ldm(frozen: bool = False):
+    """The REFERENCE's `LatentDiffusion` (ldm/models/diffusion/ddpm.py:605-), constructed as `v1-inference.yaml`
+    constructs it (crossattn conditioning, eps-parameterisation, linear schedule 0.00085 .. 0.0120, no EMA) around the
+    reference's `UNetModel` at the reduced size: its own `get_input`, `q_sample`, `apply_model`, `shared_step` /
+    `forward` / `p_losses` run — nothing of them is restated here."""
+    _stub_lightning_and_stages()
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    model = LatentDiffusion(
+        first_stage_config={"target": "salun_golden_stages." + ("FrozenLatentsAsImages" if frozen else "LatentsAsImages")},
+        cond_stage_config={"target": "salun_golden_stages." + ("FrozenPromptTable" if frozen else "PromptTable")},
+        unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": sd_glue_config()},
+        conditioning_key="crossattn", cond_stage_key="txt", first_stage_key="jpg", cond_stage_trainable=False,
+        scale_factor=1.0, timesteps=1000, linear_start=0.00085, linear_end=0.0120, image_size=8, channels=4,
+        use_ema=False, monitor=None)
+    fill_params(model.model.diffusion_model, 9100)
+    if frozen:
+        fill_params(model.first_stage_model, 9200)
+        fill_params(model.cond_stage_model, 9300)
+        assert not any(q.requires_grad for q in list(model.first_stage_model.parameters())
+                       + list(model.cond_stage_model.parameters()))
+    model.contexts = model.cond_stage_model.contexts  # the script below adds class prompts to the table
+    return model
 
 
 # ------------------------------------------------------------------ importing the scripts
@@ -303,7 +340,7 @@ def main():
             adam_state(rec.optimizers[-1], unet, out, tag)
             saved = torch.load(os.path.join("models", f"compvis-nsfw-mask-method_{method}-lr_0.0001",
                                             f"compvis-nsfw-mask-method_{method}-lr_0.0001.pt"), weights_only=False)
-            assert all(k.startswith("model.diffusion_model.") or "alphas_cumprod" in k for k in saved)
+            assert sum(k.startswith("model.diffusion_model.") for k in saved) == len(names)
             print(tag, "losses", out[f"{tag}__losses"])
 
         # ---------------------------------------------------------------- A14: certain_label (random_label.py), no mask

@@ -89,6 +89,9 @@ def parse():
                     help="reference-sequence steps timed on the host CPU, in --cpu_repeats groups (SURVEY.md D3 asks 20: "
                          "capped so the default run stays within minutes; the spread over the groups is reported)")
     ap.add_argument("--cpu_repeats", type=int, default=3)
+    ap.add_argument("--cpu_survey", action="store_true",
+                    help="the CPU baseline at the sample sizes SURVEY.md D3 asks for: 20 RL steps (4 groups of 5, ~2 min "
+                         "on 128 threads) instead of the default 6")
     ap.add_argument("--no_mask_gen", action="store_true", help="skip timing Phase A (a random mask is used)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="1 = keep cudnn.deterministic=True as the reference's setup_seed sets it (restricts MIOpen's "
@@ -302,6 +305,8 @@ def main():
         a.steps = {"resnet18": 177, "ddpm": 20, "sd": 3}[a.workload]
     if a.warmup is None:
         a.warmup = {"resnet18": 10, "ddpm": 3, "sd": 1}[a.workload]
+    if a.cpu_survey:
+        a.cpu_steps, a.cpu_repeats = 20, 4
     if a.force_collectives:
         os.environ["SALUN_FORCE_COLLECTIVES"] = "1"
     from unlearn_saliency_amd import dist as sdist

@@ -96,10 +96,9 @@ def main(argv=None):
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--digest", action="store_true",
                     help="add the SHA-256 of the parameters and the last step's loss to the line (equality tests)")
-    ap.add_argument("--cpu_steps", type=int, default=1,
-                    help="rl steps at batch 128 timed on the host cores; SURVEY.md D3 (iii) asks 3 — one step takes "
-                         "~77 s on the GPU box's 128 threads, so the default is 1 (profiles/r03_ddpm_bench.json was "
-                         "taken with --cpu_steps 3: 0.0130 steps/s)")
+    ap.add_argument("--cpu_steps", type=int, default=3,
+                    help="rl steps at batch 128 timed on the host cores: SURVEY.md D3 (iii) asks 3 (one step takes ~77 s "
+                         "on the GPU box's 128 threads, i.e. ~4 min for the baseline leg; --no_cpu_baseline skips it)")
     a = ap.parse_args(argv)
     from unlearn_saliency_amd import dist as sdist
     from unlearn_saliency_amd.DDPM.functions import load_config, get_optimizer, cycle

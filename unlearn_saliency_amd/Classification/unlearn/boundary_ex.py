@@ -13,28 +13,24 @@ from .impl import iterative_unlearn
 
 
 def expand_model(model):
-    """Replace the last nn.Linear by one with out_features + 1; old rows copied (boundary_ex.py:34-70).
-    The new layer is initialised from the CPU generator and then moved, so a run is reproducible from
-    torch.manual_seed alone on any device."""
-    last_fc_name, last_fc_layer = None, None
-    for name, module in model.named_modules():
-        if isinstance(module, nn.Linear):
-            last_fc_name, last_fc_layer = name, module
-    if last_fc_name is None:
+    """Grow the classifier by one "shadow" class (what the reference's boundary_ex.py:34-70 does to the last nn.Linear):
+    the module registered last among the model's Linear layers gets a (C+1)-row replacement whose first C rows are the
+    trained ones and whose extra row comes from a freshly initialised layer.  That fresh layer is drawn from the CPU
+    generator — the same draws as the reference's `nn.Linear(in, C + 1)` constructor on a CPU run — so a run is
+    reproducible from torch.manual_seed alone on any device."""
+    hit = next(((path, mod) for path, mod in reversed(list(model.named_modules())) if isinstance(mod, nn.Linear)), None)
+    if hit is None:
         raise ValueError("No Linear layer found in the model.")
-    num_classes = last_fc_layer.out_features
-    bias = last_fc_layer.bias is not None
-    new_fc = nn.Linear(last_fc_layer.in_features, num_classes + 1, bias=bias, dtype=last_fc_layer.weight.dtype)
-    new_fc = new_fc.to(last_fc_layer.weight.device)
+    path, trained = hit
+    dev = trained.weight.device
+    grown = nn.Linear(trained.in_features, trained.out_features + 1, bias=trained.bias is not None,
+                      dtype=trained.weight.dtype)
     with torch.no_grad():
-        new_fc.weight[:-1] = last_fc_layer.weight
-        if bias:
-            new_fc.bias[:-1] = last_fc_layer.bias
-    parts = last_fc_name.split(".")
-    owner = model
-    for part in parts[:-1]:
-        owner = getattr(owner, part)
-    setattr(owner, parts[-1], new_fc)
+        grown.weight = nn.Parameter(torch.cat([trained.weight.detach(), grown.weight[-1:].to(dev)], dim=0))
+        if trained.bias is not None:
+            grown.bias = nn.Parameter(torch.cat([trained.bias.detach(), grown.bias[-1:].to(dev)], dim=0))
+    parent, _, leaf = path.rpartition(".")
+    setattr(model.get_submodule(parent) if parent else model, leaf, grown)
 
 
 @iterative_unlearn

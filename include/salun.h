@@ -460,6 +460,59 @@ int salun_image_batch(const uint8_t *data /*dev*/, const int64_t *idx /*dev*/,
                       float *out /*dev*/, int64_t B, int H, int W, int C, int pad,
                       salun_stream_t stream);
 
+/* ----------------------------------------------------------------- K15 --
+ * fp32 GEMMs on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains; results differ from any other fp32
+ * GEMM only by summation order) — the Linear layers and the fp32 attention of the diffusion U-Nets, which the
+ * reference runs as library GEMMs behind nn.Linear / torch.bmm / einsum:
+ *   DDPM/models/diffusion.py:85-145 (temb / cemb dense layers, temb_cemb_proj of every ResnetBlock), :148-192 (AttnBlock);
+ *   SD/ldm/modules/attention.py:37-75,149-200, SD/ldm/modules/diffusionmodules/openaimodel.py:428-520 (fp32 configuration).
+ *
+ * One call computes a TABLE of problems
+ *      C_j[M_j, N_j]  (+)=  alpha * sum_{s in segments(j)} A_s . B_s^T   + bias_j[column]
+ * with  A_s(i, k) = A[i * a_i + k * a_k],  B_s(j, k) = B[j * b_j + k * b_k]  (element strides, any sign of "transposed"):
+ *   x.W^T (forward), dY.W (input gradient), dY^T.x (weight gradient, `accumulate` adds into the flat gradient) and the
+ *   channel-major attention operands of the DDPM are the same kernel without a transposing copy.  Several jobs in one
+ *   call share the launch (the DDPM's 22 per-block embedding projections); several segments of one job chain their
+ *   reductions (the input gradient of those projections: sum_g dproj_g . W_g).
+ * Batch: batch_outer x batch_inner instances, instance (o, i) offsets every A / B / C pointer by
+ *   o * strides[0|2|4] + i * strides[1|3|5] elements (a_bo a_bi b_bo b_bi c_bo c_bi); batch_strides may be NULL when
+ *   there is one instance.
+ * Under-filled launches split the reduction into fp32 partial images in `ws` (salun_gemm_f32_workspace_bytes; with a
+ * smaller / NULL workspace the call still works, unsplit) folded in a fixed order: no float atomics, deterministic.
+ * Limits: njobs <= SALUN_GEMM_MAX_JOBS, nsegs <= SALUN_GEMM_MAX_SEGS, batch <= 65535. */
+#define SALUN_GEMM_MAX_JOBS 32
+#define SALUN_GEMM_MAX_SEGS 32
+typedef struct {
+  const float *A /*dev*/, *B /*dev*/;
+  int32_t K;                  /* reduction length of this segment */
+  int32_t a_i, a_k, b_j, b_k; /* element strides */
+} salun_gemm_seg_t;
+typedef struct {
+  float *C /*dev*/;
+  const float *bias /*dev or NULL: one value per column*/;
+  int32_t M, N, ldc;
+  int32_t seg0, nseg;  /* this job's segments: segs[seg0 .. seg0 + nseg) */
+  int32_t accumulate;  /* 0: C = result, 1: C += result */
+} salun_gemm_job_t;
+size_t salun_gemm_f32_workspace_bytes(const salun_gemm_job_t *jobs /*host*/, int njobs,
+                                      const salun_gemm_seg_t *segs /*host*/, int nsegs,
+                                      int batch_outer, int batch_inner);
+int salun_gemm_f32(const salun_gemm_job_t *jobs /*host*/, int njobs, const salun_gemm_seg_t *segs /*host*/, int nsegs,
+                   int batch_outer, int batch_inner, const int64_t *batch_strides /*host[6] or NULL*/,
+                   double alpha, void *ws /*dev or NULL*/, size_t ws_bytes, salun_stream_t stream);
+/* out[j] (+)= sum_i x[i * ld + j]: the bias gradient of a Linear layer (the reference: autograd's sum over the token
+ * dimension behind nn.Linear).  Two deterministic stages (row slabs, then the slabs in index order). */
+size_t salun_colsum_f32_workspace_bytes(int64_t M, int N);
+int salun_colsum_f32(const float *x /*dev*/, float *out /*dev*/, int64_t M, int N, int64_t ld, int accumulate,
+                     void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+/* Row softmax in place: s[r][0..n) <- softmax(s[r][0..n)), rows of leading dimension ld (the P between the two GEMMs of
+ * an fp32 attention: DDPM/models/diffusion.py:176, SD attention.py:185).  One wave per row. */
+int salun_softmax_rows(float *s /*dev*/, int64_t rows, int n, int ld, salun_stream_t stream);
+/* Its backward, written over dp:  dS = scale * P * (dP - sum_j dP_j P_j)  (scale: the attention's 1/sqrt(d), so the two
+ * gradient GEMMs that follow need no extra pass). */
+int salun_softmax_rows_backward(const float *p /*dev*/, float *dp /*dev*/, int64_t rows, int n, int ld,
+                                double scale, salun_stream_t stream);
+
 /* Dropout whose keep decision is a function of (seed, GLOBAL element index) only — replaces
  * `nn.Dropout` in the DDPM ResnetBlock (DDPM/models/diffusion.py:108,124: `h = self.dropout(h)`), which under the
  * reference's nn.DataParallel draws independently per replica (runners/diffusion.py:504).

@@ -104,15 +104,18 @@ class ResnetBlock(nn.Module):
             else:
                 self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
 
-    def forward(self, x, emb_act):
-        """emb_act = swish([temb ‖ cemb]) — identical for every block, computed once per forward."""
+    def forward(self, x, emb_act, proj=None):
+        """emb_act = swish([temb ‖ cemb]) — identical for every block, computed once per forward.
+        proj: `self.temb_cemb_proj(emb_act)` when the model computed all blocks' projections in one grouped launch."""
         if self.fused_node:
             from ...resblock import fused_diffusion_resnet_block
-            out = fused_diffusion_resnet_block(self, x, emb_act)
+            out = fused_diffusion_resnet_block(self, x, emb_act, proj)
             if out is not None:
                 return out
+        if proj is None:
+            proj = self.temb_cemb_proj(emb_act)
         h = self.conv1(fused_gn_act(x, self.norm1, silu=True))  # swish(norm1(x)) as one kernel
-        h = h + self.temb_cemb_proj(emb_act)[:, :, None, None]
+        h = h + proj[:, :, None, None]
         h = self.conv2(self.dropout(fused_gn_act(h, self.norm2, silu=True)))
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
@@ -125,6 +128,7 @@ class AttnBlock(nn.Module):
     def __init__(self, in_channels):
         super().__init__()
         self.in_channels = in_channels
+        self.own_gemm = False  # set by conv.use_salun_convs(model): attention on this package's fp32 GEMM (K15)
         self.norm = group_norm(in_channels)
         self.q = nn.Conv2d(in_channels, in_channels, 1)
         self.k = nn.Conv2d(in_channels, in_channels, 1)
@@ -134,8 +138,16 @@ class AttnBlock(nn.Module):
     def forward(self, x):
         b, c, hh, ww = x.shape
         h = fused_gn_act(x, self.norm, silu=False)
-        tok = lambda t: t.reshape(b, 1, c, hh * ww).transpose(2, 3)  # (b, 1, hw, c)
-        o = F.scaled_dot_product_attention(tok(self.q(h)), tok(self.k(h)), tok(self.v(h)), scale=float(c) ** -0.5)
+        tok = lambda t: t.reshape(b, 1, c, hh * ww).transpose(2, 3)  # (b, 1, hw, c): channel-major memory, tokens contiguous
+        q, k, v = tok(self.q(h)), tok(self.k(h)), tok(self.v(h))
+        if self.own_gemm:
+            from ... import gemm
+            if gemm.attention_supported(q, k, v):
+                # GEMM -> row softmax -> GEMM on the fp32 matrix-core kernel, reading q / k / v where the 1x1
+                # convolutions left them and writing o straight back in NCHW (no transposing copy either side)
+                o = gemm.attention_f32(q, k, v, float(c) ** -0.5)
+                return x + self.proj_out(o.transpose(2, 3).reshape(b, c, hh, ww))
+        o = F.scaled_dot_product_attention(q, k, v, scale=float(c) ** -0.5)
         o = o.transpose(2, 3).reshape(b, c, hh, ww).contiguous()  # back to NCHW (the reshape alone is a channels-last view)
         return x + self.proj_out(o)
 
@@ -158,6 +170,7 @@ class Conditional_Model(nn.Module):
         self.num_resolutions, self.num_res_blocks = len(ch_mult), nrb
         self.resolution, self.in_channels = dc.image_size, mc.in_channels
         self.cond_drop_prob = mc.cond_drop_prob
+        self.own_gemm = False  # set by conv.use_salun_convs(model): Linear layers on K15, projections grouped
 
         def dense_pair(n_in, n_hidden):
             holder = nn.Module()
@@ -233,6 +246,20 @@ class Conditional_Model(nn.Module):
         null_logits = self._forward(x, t, c, cond_drop_prob=1.0)
         return (1 + cond_scale) * logits - cond_scale * null_logits
 
+    def _projections(self, emb_act):
+        """Every ResnetBlock adds Linear(emb_act) of the SAME activation (reference models/diffusion.py:120): with the
+        own GEMM all 22 are one grouped launch (and one / one / 22-in-one in backward) instead of 22 library GEMMs with
+        their bias adds, bias-gradient sums and AccumulateGrad launches.  -> {block: projection}, {} otherwise."""
+        if not (self.own_gemm and emb_act.is_cuda and emb_act.dtype == torch.float32) or torch.is_autocast_enabled():
+            return {}
+        from ... import gemm
+        blocks = self.__dict__.get("_resblocks")
+        if blocks is None:
+            blocks = [m for m in self.modules() if isinstance(m, ResnetBlock)]
+            self.__dict__["_resblocks"] = blocks
+        outs = gemm.grouped_linear(emb_act, [b.temb_cemb_proj for b in blocks])
+        return dict(zip(blocks, outs))
+
     def _forward(self, x, t, c, cond_drop_prob=None):
         assert x.shape[2] == x.shape[3] == self.resolution
         batch = x.shape[0]
@@ -246,23 +273,25 @@ class Conditional_Model(nn.Module):
             cemb = torch.where(keep[:, None], cemb, self.null_classes_emb[None, :].expand(batch, -1))
         cemb = self.cemb.dense[1](swish(self.cemb.dense[0](cemb)))
         emb_act = swish(torch.cat([temb, cemb], dim=-1))
+        proj = self._projections(emb_act)
 
         hs = [self.conv_in(x)]
         for lvl, level in enumerate(self.down):
             for i, blk in enumerate(level.block):
-                h = blk(hs[-1], emb_act)
+                h = blk(hs[-1], emb_act, proj.get(blk))
                 if len(level.attn) > 0:
                     h = level.attn[i](h)
                 hs.append(h)
             if lvl != self.num_resolutions - 1:
                 hs.append(level.downsample(hs[-1]))
 
-        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(hs[-1], emb_act)), emb_act)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(hs[-1], emb_act, proj.get(self.mid.block_1))), emb_act,
+                             proj.get(self.mid.block_2))
 
         for lvl in reversed(range(self.num_resolutions)):
             level = self.up[lvl]
             for i, blk in enumerate(level.block):
-                h = blk(torch.cat([h, hs.pop()], dim=1), emb_act)
+                h = blk(torch.cat([h, hs.pop()], dim=1), emb_act, proj.get(blk))
                 if len(level.attn) > 0:
                     h = level.attn[i](h)
             if lvl != 0:

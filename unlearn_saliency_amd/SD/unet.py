@@ -124,6 +124,7 @@ class CrossAttention(nn.Module):
         inner = dim_head * heads
         context_dim = query_dim if context_dim is None else context_dim
         self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        self.own_gemm = False  # set by conv.use_salun_convs(model) (fp32 configuration): attention on K15
         self.to_q = nn.Linear(query_dim, inner, bias=False)
         self.to_k = nn.Linear(context_dim, inner, bias=False)
         self.to_v = nn.Linear(context_dim, inner, bias=False)
@@ -139,6 +140,14 @@ class CrossAttention(nn.Module):
             o = ops.attention(heads(q), heads(k.to(torch.bfloat16)), heads(v.to(torch.bfloat16)), self.scale)
             return self.to_out(o.view(b, n, self.heads * self.dim_head))
         split = lambda t: t.view(b, t.shape[1], self.heads, self.dim_head).transpose(1, 2)  # (b, h, tokens, d)
+        if self.own_gemm:
+            from .. import gemm
+            qs, ks, vs = split(q), split(k), split(v)
+            if gemm.attention_supported(qs, ks, vs):
+                # fp32 configuration: GEMM -> row softmax -> GEMM on the fp32 matrix-core kernel over the [b, h, n, d]
+                # views of the projections (no head-splitting copies; o comes back in q's layout)
+                o = gemm.attention_f32(qs, ks, vs, self.scale)
+                return self.to_out(o.transpose(1, 2).reshape(b, n, self.heads * self.dim_head))
         o = F.scaled_dot_product_attention(split(q), split(k), split(v), scale=self.scale)
         return self.to_out(o.transpose(1, 2).reshape(b, n, self.heads * self.dim_head))
 

@@ -26,6 +26,22 @@ SALUN_TOPK_VALUES_ONLY = 2
 c_void_p, c_int, c_int64, c_uint64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
 c_double, c_size_t = ctypes.c_double, ctypes.c_size_t
 
+class GemmSeg(ctypes.Structure):
+    """salun_gemm_seg_t"""
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("K", ctypes.c_int32), ("a_i", ctypes.c_int32),
+                ("a_k", ctypes.c_int32), ("b_j", ctypes.c_int32), ("b_k", ctypes.c_int32)]
+
+
+class GemmJob(ctypes.Structure):
+    """salun_gemm_job_t"""
+    _fields_ = [("C", c_void_p), ("bias", c_void_p), ("M", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("ldc", ctypes.c_int32), ("seg0", ctypes.c_int32), ("nseg", ctypes.c_int32),
+                ("accumulate", ctypes.c_int32)]
+
+
+SALUN_GEMM_MAX_JOBS = 32
+SALUN_GEMM_MAX_SEGS = 32
+
 # name -> (restype, argtypes); mirrors include/salun.h one to one
 # (tests/test_cabi.py checks this table against the header and the .so).
 SIGNATURES = {
@@ -98,6 +114,14 @@ SIGNATURES = {
     "salun_ewc_penalty_grad": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "salun_image_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                   c_int, c_void_p]),
+    "salun_gemm_f32_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmJob), c_int, ctypes.POINTER(GemmSeg), c_int, c_int,
+                                                  c_int]),
+    "salun_gemm_f32": (c_int, [ctypes.POINTER(GemmJob), c_int, ctypes.POINTER(GemmSeg), c_int, c_int, c_int,
+                               ctypes.POINTER(c_int64), c_double, c_void_p, c_size_t, c_void_p]),
+    "salun_colsum_f32_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "salun_colsum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "salun_softmax_rows": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "salun_softmax_rows_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_double, c_void_p]),
     "salun_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_uint64, c_void_p, c_void_p]),
     "salun_u64_add": (c_int, [c_void_p, c_uint64, c_void_p]),
     "salun_fill_uniform": (c_int, [c_void_p, c_int64, c_uint64, c_double, c_double, c_void_p]),

@@ -27,6 +27,8 @@ _STRICT = [False]
 
 # SALUN_BLOCK_NODES=0: keep the diffusion ResnetBlocks as separate autograd nodes (A/B switch for the benchmarks)
 _BLOCK_NODES = [os.environ.get("SALUN_BLOCK_NODES", "1") != "0"]
+# SALUN_OWN_GEMM=0: keep the diffusion U-Nets' Linear layers and fp32 attention on the library (A/B switch)
+_OWN_GEMM = [os.environ.get("SALUN_OWN_GEMM", "1") != "0"]
 
 
 def strict(on: bool = True) -> None:
@@ -151,6 +153,13 @@ def use_salun_convs(model: nn.Module) -> int:
     for mod in model.modules():
         if hasattr(mod, "fused_node") and hasattr(mod, "temb_cemb_proj"):  # DDPM ResnetBlock: one autograd node
             mod.fused_node = _BLOCK_NODES[0]
+    own_gemm = [m for m in model.modules() if hasattr(m, "own_gemm")]
+    if own_gemm and _OWN_GEMM[0]:
+        # diffusion U-Nets: attention and every Linear layer on this package's fp32 MFMA GEMM (K15, gemm.py) as well
+        from .gemm import use_salun_linears
+        for m in own_gemm:
+            m.own_gemm = True
+        use_salun_linears(model)
     owners = {id(m.conv) for m in model.modules() if getattr(m, "use_mfma", False) and hasattr(m, "conv")}
     for mod in model.modules():
         if type(mod) is nn.Conv2d and _eligible(mod) and id(mod) not in owners:

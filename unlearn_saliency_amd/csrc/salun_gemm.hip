@@ -1,0 +1,490 @@
+// salun_gemm.hip — fp32 GEMMs of the diffusion U-Nets on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+// FMA chains), and the row softmax between the two GEMMs of an fp32 attention.  gfx950 only.
+//
+// What runs here (reference modules replaced — the library GEMMs PyTorch dispatches for them):
+//   * Linear layers:  DDPM/models/diffusion.py:85-145 (temb / cemb dense pairs, every ResnetBlock's temb_cemb_proj),
+//     SD/ldm/modules/attention.py:37-75,149-200 and openaimodel.py:428-520 in the fp32 configuration;
+//   * fp32 attention: DDPM/models/diffusion.py:148-192 (AttnBlock: bmm -> softmax -> bmm over 256 tokens),
+//     SD/ldm/modules/attention.py:168-192 (einsum -> softmax -> einsum).
+//
+// ONE kernel computes a TABLE of problems  C_j[M_j, N_j] (+)= alpha * sum over segments s of A_s . B_s^T  (+ bias_j):
+//   job      an output matrix (row-major, leading dimension ldc), optional bias per column, write or accumulate;
+//   segment  one (A, B, K) pair of a job's reduction: A(i, k) = A[i * a_i + k * a_k], B(j, k) = B[j * b_j + k * b_k]
+//            — arbitrary element strides, so x.W^T, dY.W, dY^T.x and the channel-major attention operands of the DDPM
+//            (tokens contiguous) are all the same kernel with no transposing copy.
+// A plain GEMM is 1 job x 1 segment.  The DDPM's 22 embedding projections (one per ResnetBlock, all reading the same
+// [batch, 1024] activation) are 22 jobs in one launch; their input gradient sum_g dproj_g . W_g is 1 job x 22 segments;
+// their weight gradients 22 jobs again — 3 launches per pass instead of 66.  A batch dimension (two-level: outer x
+// inner strides, i.e. image x head) covers attention.
+//
+// Tiling: 256 threads = 2 x 2 waves, each wave WT x WT MFMA tiles of 32 x 32 (block tile 64 WT square), reduction in
+// chunks of 16 staged through LDS rows of 17 floats (conflict-free ds_read_b32 across the 32 rows of an operand);
+// the next chunk's global loads are issued before the current chunk's MFMAs.  Loads are 16-byte wherever a unit-stride
+// dimension and the alignment allow (mode chosen per segment on the host), scalar otherwise.  Under-filled launches
+// split the reduction over blockIdx.z into fp32 partial images that a second kernel folds in a fixed order (no float
+// atomics anywhere: results are deterministic).
+#include "salun_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MAXJ = SALUN_GEMM_MAX_JOBS;
+constexpr int MAXS = SALUN_GEMM_MAX_SEGS;
+constexpr int BK = 16;
+constexpr int LDK = BK + 1;
+
+struct Seg {
+  const float *A, *B;
+  int K, a_i, a_k, b_j, b_k;
+  int chunk0;        // index of this segment's first chunk in the job's chunk list
+  int amode, bmode;  // 0 scalar, 1 16-byte loads along k (stride_k == 1), 2 16-byte loads along the row index
+};
+struct Job {
+  float *C;
+  const float *bias;
+  int M, N, ldc, seg0, nseg, nchunks, tile0, tiles_n, accumulate;
+  long long ws_off;  // element offset of this job's partial image inside one split slab
+};
+struct Args {
+  Job job[MAXJ];
+  Seg seg[MAXS];
+  int njobs, nsplit, batch_inner;
+  long long a_bo, a_bi, b_bo, b_bi, c_bo, c_bi;  // batch strides (outer, inner) in elements
+  float alpha;
+  float *ws;
+  long long ws_slab;   // elements per split slab (all jobs, all batches)
+  long long ws_batch;  // elements per batch inside a slab
+};
+
+template <int NV>
+struct Stage {
+  float4 v[NV];
+};
+
+// One operand's share of a chunk for this thread: rows [r0, r0 + rows) x k [k0, k0 + BK), element (row, k) at
+// p[row * s_row + k * s_k]; out-of-range elements are zero.
+template <int BT, int NV>
+__device__ __forceinline__ void stage_load(Stage<NV> &st, const float *__restrict__ p, int s_row, int s_k, int r0,
+                                           int nrows, int k0, int nk, int mode, int tid) {
+#pragma unroll
+  for (int r = 0; r < NV; ++r) {
+    const int e = tid + 256 * r;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 1) {  // four consecutive k of one row
+      const int row = e >> 2, kk = (e & 3) * 4;
+      const int gr = r0 + row, gk = k0 + kk;
+      if (gr < nrows && gk < nk) {
+        const float *q = p + (long long)gr * s_row + gk;
+        if (gk + 3 < nk) val = *reinterpret_cast<const float4 *>(q);
+        else {
+          val.x = q[0];
+          if (gk + 1 < nk) val.y = q[1];
+          if (gk + 2 < nk) val.z = q[2];
+        }
+      }
+    } else if (mode == 2) {  // four consecutive rows at one k
+      constexpr int F4 = BT / 4;
+      const int kk = e / F4, row = (e % F4) * 4;
+      const int gr = r0 + row, gk = k0 + kk;
+      if (gr < nrows && gk < nk) {
+        const float *q = p + (long long)gk * s_k + gr;
+        if (gr + 3 < nrows) val = *reinterpret_cast<const float4 *>(q);
+        else {
+          val.x = q[0];
+          if (gr + 1 < nrows) val.y = q[1];
+          if (gr + 2 < nrows) val.z = q[2];
+        }
+      }
+    } else {  // scalar: element e*4+c -> (row, k) = (idx / 16, idx % 16)
+      float t[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int idx = e * 4 + c, row = idx >> 4, kk = idx & 15;
+        const int gr = r0 + row, gk = k0 + kk;
+        t[c] = (gr < nrows && gk < nk) ? p[(long long)gr * s_row + (long long)gk * s_k] : 0.f;
+      }
+      val = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    st.v[r] = val;
+  }
+}
+
+template <int BT, int NV>
+__device__ __forceinline__ void stage_store(float *__restrict__ lds, const Stage<NV> &st, int mode, int tid) {
+#pragma unroll
+  for (int r = 0; r < NV; ++r) {
+    const int e = tid + 256 * r;
+    const float4 v = st.v[r];
+    if (mode == 1) {
+      float *d = lds + (e >> 2) * LDK + (e & 3) * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else if (mode == 2) {
+      constexpr int F4 = BT / 4;
+      float *d = lds + ((e % F4) * 4) * LDK + e / F4;
+      d[0] = v.x; d[LDK] = v.y; d[2 * LDK] = v.z; d[3 * LDK] = v.w;
+    } else {
+      const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int idx = e * 4 + c;
+        lds[(idx >> 4) * LDK + (idx & 15)] = t[c];
+      }
+    }
+  }
+}
+
+template <int WT>
+__global__ __launch_bounds__(256) void k_gemm_f32(const Args a) {
+  constexpr int BT = 64 * WT;          // block tile (square)
+  constexpr int NV = BT * BK / 4 / 256;  // float4 items per thread and operand: WT
+  __shared__ float As[BT * LDK];
+  __shared__ float Bs[BT * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- which job / tile / batch / split
+  int j = 0;
+  const int tile = blockIdx.x;
+  while (j + 1 < a.njobs && tile >= a.job[j + 1].tile0) ++j;
+  const Job J = a.job[j];
+  const int t = tile - J.tile0;
+  const int m0 = (t / J.tiles_n) * BT, n0 = (t % J.tiles_n) * BT;
+  const int bz = blockIdx.y;
+  const int bo = bz / a.batch_inner, bi = bz - bo * a.batch_inner;
+  const long long a_off = (long long)bo * a.a_bo + (long long)bi * a.a_bi;
+  const long long b_off = (long long)bo * a.b_bo + (long long)bi * a.b_bi;
+  const long long c_off = (long long)bo * a.c_bo + (long long)bi * a.c_bi;
+  const int z = blockIdx.z;
+  const int per = (J.nchunks + a.nsplit - 1) / a.nsplit;
+  const int c_lo = z * per, c_hi = (c_lo + per < J.nchunks) ? c_lo + per : J.nchunks;
+
+  f32x16 acc[WT][WT];
+#pragma unroll
+  for (int x = 0; x < WT; ++x)
+#pragma unroll
+    for (int y = 0; y < WT; ++y)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
+
+  if (c_lo < c_hi) {
+    int s = J.seg0;
+    while (s + 1 < J.seg0 + J.nseg && a.seg[s + 1].chunk0 <= c_lo) ++s;
+    Seg S = a.seg[s];
+    Stage<NV> ra, rb;
+    stage_load<BT, NV>(ra, S.A + a_off, S.a_i, S.a_k, m0, J.M, (c_lo - S.chunk0) * BK, S.K, S.amode, tid);
+    stage_load<BT, NV>(rb, S.B + b_off, S.b_j, S.b_k, n0, J.N, (c_lo - S.chunk0) * BK, S.K, S.bmode, tid);
+    int amode = S.amode, bmode = S.bmode;
+    for (int c = c_lo; c < c_hi; ++c) {
+      stage_store<BT, NV>(As, ra, amode, tid);
+      stage_store<BT, NV>(Bs, rb, bmode, tid);
+      __syncthreads();
+      if (c + 1 < c_hi) {  // the next chunk's loads fly while this one is multiplied
+        if (s + 1 < J.seg0 + J.nseg && a.seg[s + 1].chunk0 <= c + 1) { ++s; S = a.seg[s]; }
+        stage_load<BT, NV>(ra, S.A + a_off, S.a_i, S.a_k, m0, J.M, (c + 1 - S.chunk0) * BK, S.K, S.amode, tid);
+        stage_load<BT, NV>(rb, S.B + b_off, S.b_j, S.b_k, n0, J.N, (c + 1 - S.chunk0) * BK, S.K, S.bmode, tid);
+        amode = S.amode; bmode = S.bmode;
+      }
+      const float *ar = As + (wm * 32 * WT + lo) * LDK + hi;
+      const float *br = Bs + (wn * 32 * WT + lo) * LDK + hi;
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float av[WT], bv[WT];
+#pragma unroll
+        for (int x = 0; x < WT; ++x) { av[x] = ar[x * 32 * LDK + 2 * kk]; bv[x] = br[x * 32 * LDK + 2 * kk]; }
+#pragma unroll
+        for (int x = 0; x < WT; ++x)
+#pragma unroll
+          for (int y = 0; y < WT; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: D[i][j] of a 32x32 tile sits in lane (j = lo, half = hi), register v: i = (v&3) + 8 (v>>2) + 4 hi
+  const bool direct = a.nsplit == 1;
+  float *out = direct ? J.C + c_off
+                      : a.ws + (long long)z * a.ws_slab + (long long)bz * a.ws_batch + J.ws_off;
+  const int ld = direct ? J.ldc : J.N;
+#pragma unroll
+  for (int x = 0; x < WT; ++x)
+#pragma unroll
+    for (int y = 0; y < WT; ++y) {
+      const int jj = n0 + wn * 32 * WT + y * 32 + lo;
+      if (jj >= J.N) continue;
+      const float bsv = (direct && J.bias) ? J.bias[jj] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int ii = m0 + wm * 32 * WT + x * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+        if (ii >= J.M) continue;
+        float *d = out + (long long)ii * ld + jj;
+        if (direct) {
+          const float r = acc[x][y][v] * a.alpha + bsv;
+          *d = J.accumulate ? (*d + r) : r;
+        } else {
+          *d = acc[x][y][v];
+        }
+      }
+    }
+}
+
+// folds the split slabs in index order, then alpha / bias / accumulate as the direct epilogue does
+__global__ __launch_bounds__(256) void k_gemm_finish(const Args a) {
+  const Job J = a.job[blockIdx.y];
+  const int bz = blockIdx.z;
+  const int bo = bz / a.batch_inner, bi = bz - bo * a.batch_inner;
+  float *C = J.C + (long long)bo * a.c_bo + (long long)bi * a.c_bi;
+  const float *w = a.ws + (long long)bz * a.ws_batch + J.ws_off;
+  const long long total = (long long)J.M * J.N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    float s = w[e];
+    for (int zz = 1; zz < a.nsplit; ++zz) s += w[(long long)zz * a.ws_slab + e];
+    const int i = (int)(e / J.N), jj = (int)(e - (long long)i * J.N);
+    const float r = s * a.alpha + (J.bias ? J.bias[jj] : 0.f);
+    float *d = C + (long long)i * J.ldc + jj;
+    *d = J.accumulate ? (*d + r) : r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ row softmax
+// One wave per row (rows of n <= ld contiguous floats): three passes over a row that is a few KiB and stays in L2.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_softmax_rows(float *__restrict__ s, long long rows, int n, int ld) {
+  const int lane = threadIdx.x & 63;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+    float *row = s + r * ld;
+    float m = -INFINITY;
+    for (int jj = lane; jj < n; jj += 64) m = fmaxf(m, row[jj]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int jj = lane; jj < n; jj += 64) {
+      const float e = __expf(row[jj] - m);
+      row[jj] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int jj = lane; jj < n; jj += 64) row[jj] *= inv;
+  }
+}
+
+// dS = scale * P * (dP - sum_j dP_j P_j), written over dP
+__global__ __launch_bounds__(256) void k_softmax_rows_bwd(const float *__restrict__ p, float *__restrict__ dp, long long rows,
+                                                          int n, int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+    const float *pr = p + r * ld;
+    float *dr = dp + r * ld;
+    float dot = 0.f;
+    for (int jj = lane; jj < n; jj += 64) dot += pr[jj] * dr[jj];
+    dot = wave_sum(dot);
+    for (int jj = lane; jj < n; jj += 64) dr[jj] = scale * (pr[jj] * (dr[jj] - dot));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[j] (+)= sum_i x[i * ld + j] — the bias gradient of a Linear layer.  Stage 1: a workgroup owns 64 columns x one
+// slab of rows (a wave reads 64 consecutive floats of a row), 4 row lanes folded through LDS; stage 2 folds the slabs
+// in index order.
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ x, float *__restrict__ part, long long M,
+                                                        int N, long long ld, int slabs) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, slab = blockIdx.y;
+  const long long per = (M + slabs - 1) / slabs;
+  const long long r0 = slab * per, r1 = (r0 + per < M) ? r0 + per : M;
+  float acc = 0.f;
+  if (col < N)
+    for (long long r = r0 + rl; r < r1; r += 4) acc += x[r * ld + col];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && col < N) part[(long long)slab * N + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ part, float *__restrict__ out, int N, int slabs,
+                                                      int accumulate) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  float t = 0.f;
+  for (int s2 = 0; s2 < slabs; ++s2) t += part[(long long)s2 * N + col];
+  out[col] = accumulate ? out[col] + t : t;
+}
+inline int colsum_slabs(long long M, int N) {
+  long long s = 1024 / ((N + 63) / 64);  // ~1024 workgroups
+  if (s < 1) s = 1;
+  if (s > (M + 15) / 16) s = (M + 15) / 16;  // >= 16 rows per slab
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
+}
+
+bool aligned16_stride(const void *p, long long bo, long long bi, int s) {
+  return salun_aligned16(p) && (bo % 4 == 0) && (bi % 4 == 0) && (s % 4 == 0);
+}
+
+}  // namespace
+
+// ================================================================== C-ABI =======
+static int gemm_tile_for(const salun_gemm_job_t *jobs, int njobs, int batch) {
+  // 128 x 128 block tiles when they alone fill the chip, else 64 x 64
+  long long t128 = 0;
+  for (int j = 0; j < njobs; ++j) t128 += (long long)((jobs[j].M + 127) / 128) * ((jobs[j].N + 127) / 128);
+  return (t128 * batch >= 512) ? 128 : 64;
+}
+
+static int gemm_plan(const salun_gemm_job_t *jobs, int njobs, const salun_gemm_seg_t *segs, int nsegs, int batch,
+                     int *tile_out, long long *tiles_out, int *split_out, long long *out_elems_out) {
+  if (!jobs || !segs || njobs < 1 || njobs > MAXJ || nsegs < 1 || nsegs > MAXS || batch < 1) return SALUN_EINVAL;
+  const int bt = gemm_tile_for(jobs, njobs, batch);
+  long long tiles = 0, out_elems = 0;
+  int min_chunks = 1 << 30;
+  for (int j = 0; j < njobs; ++j) {
+    const salun_gemm_job_t &J = jobs[j];
+    if (J.M < 1 || J.N < 1 || J.nseg < 1 || J.seg0 < 0 || J.seg0 + J.nseg > nsegs || !J.C || J.ldc < J.N) return SALUN_EINVAL;
+    tiles += (long long)((J.M + bt - 1) / bt) * ((J.N + bt - 1) / bt);
+    out_elems += (long long)J.M * J.N;
+    int chunks = 0;
+    for (int s = J.seg0; s < J.seg0 + J.nseg; ++s) {
+      if (segs[s].K < 1 || !segs[s].A || !segs[s].B) return SALUN_EINVAL;
+      chunks += (segs[s].K + BK - 1) / BK;
+    }
+    if (chunks < min_chunks) min_chunks = chunks;
+  }
+  // split the reduction while the launch leaves the chip under-filled and every share keeps >= 4 chunks
+  int split = 1;
+  const long long wgs = tiles * batch;
+  if (wgs < 256) {
+    split = (int)(512 / (wgs < 1 ? 1 : wgs));
+    if (split > 16) split = 16;
+    while (split > 1 && min_chunks / split < 4) --split;
+  }
+  *tile_out = bt; *tiles_out = tiles; *split_out = split < 1 ? 1 : split; *out_elems_out = out_elems;
+  return SALUN_OK;
+}
+
+SALUN_EXPORT size_t salun_gemm_f32_workspace_bytes(const salun_gemm_job_t *jobs, int njobs, const salun_gemm_seg_t *segs,
+                                                   int nsegs, int batch_outer, int batch_inner) {
+  int bt, split;
+  long long tiles, out_elems;
+  if (batch_outer < 1 || batch_inner < 1) return 0;
+  if (gemm_plan(jobs, njobs, segs, nsegs, batch_outer * batch_inner, &bt, &tiles, &split, &out_elems) != SALUN_OK) return 0;
+  return split > 1 ? sizeof(float) * (size_t)split * (size_t)out_elems * (size_t)(batch_outer * batch_inner) : 0;
+}
+
+SALUN_EXPORT int salun_gemm_f32(const salun_gemm_job_t *jobs, int njobs, const salun_gemm_seg_t *segs, int nsegs,
+                                int batch_outer, int batch_inner, const int64_t *batch_strides /* a_bo a_bi b_bo b_bi c_bo c_bi */,
+                                double alpha, void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (batch_outer < 1 || batch_inner < 1) return SALUN_EINVAL;
+  const int batch = batch_outer * batch_inner;
+  if (batch > 1 && !batch_strides) return SALUN_EINVAL;
+  int bt, split;
+  long long tiles, out_elems;
+  const int rc = gemm_plan(jobs, njobs, segs, nsegs, batch, &bt, &tiles, &split, &out_elems);
+  if (rc != SALUN_OK) return rc;
+  if (batch > 65535 || tiles > 0x7fffffffLL) return SALUN_EINVAL;
+  if (split > 1) {
+    const size_t need = sizeof(float) * (size_t)split * (size_t)out_elems * (size_t)batch;
+    if (!ws || ws_bytes < need || !salun_aligned4(ws)) split = 1;  // no room: one workgroup per tile does the whole reduction
+  }
+  Args a;
+  a.njobs = njobs; a.nsplit = split; a.batch_inner = batch_inner;
+  a.a_bo = a.a_bi = a.b_bo = a.b_bi = a.c_bo = a.c_bi = 0;
+  if (batch_strides) {
+    a.a_bo = batch_strides[0]; a.a_bi = batch_strides[1]; a.b_bo = batch_strides[2];
+    a.b_bi = batch_strides[3]; a.c_bo = batch_strides[4]; a.c_bi = batch_strides[5];
+  }
+  a.alpha = (float)alpha;
+  a.ws = static_cast<float *>(ws);
+  a.ws_batch = out_elems;
+  a.ws_slab = out_elems * batch;
+  long long tile0 = 0, ws_off = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const salun_gemm_job_t &J = jobs[j];
+    Job &d = a.job[j];
+    d.C = J.C; d.bias = J.bias; d.M = J.M; d.N = J.N; d.ldc = J.ldc; d.seg0 = J.seg0; d.nseg = J.nseg;
+    d.accumulate = J.accumulate ? 1 : 0;
+    d.tile0 = (int)tile0; d.tiles_n = (J.N + bt - 1) / bt;
+    tile0 += (long long)((J.M + bt - 1) / bt) * d.tiles_n;
+    d.ws_off = ws_off; ws_off += (long long)J.M * J.N;
+    int chunk0 = 0;
+    for (int s = J.seg0; s < J.seg0 + J.nseg; ++s) {
+      const salun_gemm_seg_t &S = segs[s];
+      Seg &e = a.seg[s];
+      e.A = S.A; e.B = S.B; e.K = S.K; e.a_i = S.a_i; e.a_k = S.a_k; e.b_j = S.b_j; e.b_k = S.b_k;
+      e.chunk0 = chunk0; chunk0 += (S.K + BK - 1) / BK;
+      e.amode = (S.a_k == 1 && aligned16_stride(S.A, a.a_bo, a.a_bi, S.a_i)) ? 1
+              : (S.a_i == 1 && aligned16_stride(S.A, a.a_bo, a.a_bi, S.a_k)) ? 2 : 0;
+      e.bmode = (S.b_k == 1 && aligned16_stride(S.B, a.b_bo, a.b_bi, S.b_j)) ? 1
+              : (S.b_j == 1 && aligned16_stride(S.B, a.b_bo, a.b_bi, S.b_k)) ? 2 : 0;
+    }
+    d.nchunks = chunk0;
+  }
+  hipStream_t st = salun_hip_stream(stream);
+  const dim3 grid((unsigned)tiles, (unsigned)batch, (unsigned)split);
+  if (bt == 128) hipLaunchKernelGGL(k_gemm_f32<2>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_gemm_f32<1>, grid, dim3(256), 0, st, a);
+  SALUN_LAUNCH_CHECK();
+  if (split > 1) {
+    long long max_mn = 1;
+    for (int j = 0; j < njobs; ++j) {
+      const long long mn = (long long)jobs[j].M * jobs[j].N;
+      if (mn > max_mn) max_mn = mn;
+    }
+    long long gx = (max_mn + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_gemm_finish, dim3((unsigned)gx, (unsigned)njobs, (unsigned)batch), dim3(256), 0, st, a);
+    SALUN_LAUNCH_CHECK();
+  }
+  return SALUN_OK;
+}
+
+SALUN_EXPORT int salun_softmax_rows(float *s, int64_t rows, int n, int ld, salun_stream_t stream) {
+  if (rows < 0 || n < 1 || ld < n) return SALUN_EINVAL;
+  if (rows == 0) return SALUN_OK;
+  if (!s) return SALUN_EINVAL;
+  hipLaunchKernelGGL(k_softmax_rows, dim3(salun_grid_for(rows, 4)), dim3(256), 0, salun_hip_stream(stream), s,
+                     (long long)rows, n, ld);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+SALUN_EXPORT int salun_softmax_rows_backward(const float *p, float *dp, int64_t rows, int n, int ld, double scale,
+                                             salun_stream_t stream) {
+  if (rows < 0 || n < 1 || ld < n) return SALUN_EINVAL;
+  if (rows == 0) return SALUN_OK;
+  if (!p || !dp) return SALUN_EINVAL;
+  hipLaunchKernelGGL(k_softmax_rows_bwd, dim3(salun_grid_for(rows, 4)), dim3(256), 0, salun_hip_stream(stream), p, dp,
+                     (long long)rows, n, ld, (float)scale);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+SALUN_EXPORT size_t salun_colsum_f32_workspace_bytes(int64_t M, int N) {
+  if (M < 1 || N < 1) return 0;
+  return sizeof(float) * (size_t)colsum_slabs(M, N) * (size_t)N;
+}
+
+SALUN_EXPORT int salun_colsum_f32(const float *x, float *out, int64_t M, int N, int64_t ld, int accumulate, void *ws,
+                                  size_t ws_bytes, salun_stream_t stream) {
+  if (M < 1 || N < 1 || ld < N || !x || !out || !ws) return SALUN_EINVAL;
+  if (ws_bytes < salun_colsum_f32_workspace_bytes(M, N)) return SALUN_ENOSPC;
+  const int slabs = colsum_slabs(M, N);
+  hipStream_t st = salun_hip_stream(stream);
+  float *part = static_cast<float *>(ws);
+  hipLaunchKernelGGL(k_colsum_partial, dim3((N + 63) / 64, slabs), dim3(256), 0, st, x, part, (long long)M, N, (long long)ld,
+                     slabs);
+  SALUN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colsum_final, dim3((N + 255) / 256), dim3(256), 0, st, part, out, N, slabs, accumulate ? 1 : 0);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}

@@ -408,7 +408,7 @@ def _diffusion_block_probe(blk, shape, device) -> bool:
     return True
 
 
-def fused_diffusion_resnet_block(blk, x: torch.Tensor, emb_act: torch.Tensor):
+def fused_diffusion_resnet_block(blk, x: torch.Tensor, emb_act: torch.Tensor, proj: torch.Tensor = None):
     """`blk(x, emb_act)` as one autograd node, or None when the block cannot take this path (the module then runs
     its ordinary forward)."""
     from . import norm
@@ -422,7 +422,8 @@ def fused_diffusion_resnet_block(blk, x: torch.Tensor, emb_act: torch.Tensor):
             ok = cache[key] = _diffusion_block_structure_ok(blk) and _diffusion_block_probe(blk, tuple(x.shape), x.device)
     if not ok or not _diffusion_block_structure_ok(blk):
         return None
-    proj = blk.temb_cemb_proj(emb_act)
+    if proj is None:
+        proj = blk.temb_cemb_proj(emb_act)
     if proj.dtype != torch.float32 or tuple(proj.shape) != (x.shape[0], blk.out_channels):
         return None
     skip = None

@@ -513,6 +513,22 @@ int salun_softmax_rows(float *s /*dev*/, int64_t rows, int n, int ld, salun_stre
 int salun_softmax_rows_backward(const float *p /*dev*/, float *dp /*dev*/, int64_t rows, int n, int ld,
                                 double scale, salun_stream_t stream);
 
+/* ----------------------------------------------------------------- K16 --
+ * bf16 GEMM  y[M, N] = x[M, K] . w[N, K]^T (+ bias[N] fp32) (+ addend[M, N] bf16)  on v_mfma_f32_32x32x16_bf16, fp32
+ * accumulation, one rounding to bf16 — the Linear layers of the SD transformer blocks in the bf16 configuration
+ * (reference: autocast over SD/ldm/modules/attention.py:37-75 GEGLU / FeedForward, :149-200 to_q / to_k / to_v / to_out).
+ * x, w, addend, y: bf16 row-major; both operand tiles go global -> LDS directly (global_load_lds_dwordx4, bank swizzle on
+ * the source address).  The input gradient dX = dY . W is the same call on the transposed image (salun_pack_bf16 with
+ * transposed = 1).  Requirements: K % 64 == 0, N % 64 == 0, 16-byte aligned pointers (salun_gemm_bf16_supported);
+ * SALUN_EINVAL otherwise.  variant: 0 = choose the tile, 1..4 = pin one (A/B measurements). */
+int salun_gemm_bf16_supported(int64_t M, int N, int K);
+int salun_gemm_bf16_nt(const void *x /*dev bf16*/, const void *w /*dev bf16*/, const float *bias /*dev or NULL*/,
+                       const void *addend /*dev bf16 or NULL*/, void *y /*dev bf16*/, int64_t M, int N, int K,
+                       int variant, salun_stream_t stream);
+/* fp32 master weights w[N][K] -> the bf16 image the GEMM reads: [N][K] (transposed = 0) or [K][N] (transposed = 1).
+ * Once per optimizer step per layer. */
+int salun_pack_bf16(const float *w /*dev*/, void *wp /*dev bf16*/, int N, int K, int transposed, salun_stream_t stream);
+
 /* Dropout whose keep decision is a function of (seed, GLOBAL element index) only — replaces
  * `nn.Dropout` in the DDPM ResnetBlock (DDPM/models/diffusion.py:108,124: `h = self.dropout(h)`), which under the
  * reference's nn.DataParallel draws independently per replica (runners/diffusion.py:504).

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint as _ckpt
 
 from .. import ops
-from ..conv_bf16 import SalunConv2dBF16
+from ..conv_bf16 import SalunConv2dBF16, SalunLinearBF16
 from ..norm import _GN_TYPES, fused_gn_act
 
 
@@ -130,7 +130,17 @@ class CrossAttention(nn.Module):
         self.to_v = nn.Linear(context_dim, inner, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
 
-    def forward(self, x, context=None):
+    def _out(self, o, residual):
+        """to_out = Linear -> Dropout(0); with the own bf16 GEMM the block's residual rides in the Linear's epilogue."""
+        lin = self.to_out[0]
+        if residual is not None and isinstance(lin, SalunLinearBF16) and o.dtype == torch.bfloat16 \
+                and residual.dtype == torch.bfloat16:
+            return self.to_out[1](lin(o, addend=residual))
+        y = self.to_out(o)
+        return y if residual is None else y + residual
+
+    def forward(self, x, context=None, residual=None):
+        """`residual`: the tensor the caller adds to the result (BasicTransformerBlock's `attn(x) + x`)."""
         context = x if context is None else context
         b, n, _ = x.shape
         q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
@@ -138,7 +148,7 @@ class CrossAttention(nn.Module):
             # bf16 configuration: fused attention of csrc/salun_attn.hip reading the projections in place ([b, n, h, d] views)
             heads = lambda t: t.view(b, t.shape[1], self.heads, self.dim_head)
             o = ops.attention(heads(q), heads(k.to(torch.bfloat16)), heads(v.to(torch.bfloat16)), self.scale)
-            return self.to_out(o.view(b, n, self.heads * self.dim_head))
+            return self._out(o.view(b, n, self.heads * self.dim_head), residual)
         split = lambda t: t.view(b, t.shape[1], self.heads, self.dim_head).transpose(1, 2)  # (b, h, tokens, d)
         if self.own_gemm:
             from .. import gemm
@@ -147,9 +157,9 @@ class CrossAttention(nn.Module):
                 # fp32 configuration: GEMM -> row softmax -> GEMM on the fp32 matrix-core kernel over the [b, h, n, d]
                 # views of the projections (no head-splitting copies; o comes back in q's layout)
                 o = gemm.attention_f32(qs, ks, vs, self.scale)
-                return self.to_out(o.transpose(1, 2).reshape(b, n, self.heads * self.dim_head))
+                return self._out(o.transpose(1, 2).reshape(b, n, self.heads * self.dim_head), residual)
         o = F.scaled_dot_product_attention(split(q), split(k), split(v), scale=self.scale)
-        return self.to_out(o.transpose(1, 2).reshape(b, n, self.heads * self.dim_head))
+        return self._out(o.transpose(1, 2).reshape(b, n, self.heads * self.dim_head), residual)
 
 
 class GEGLU(nn.Module):
@@ -170,8 +180,15 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(dropout), nn.Linear(dim * mult, dim))
 
-    def forward(self, x):
-        return self.net(x)
+    def forward(self, x, residual=None):
+        """`residual`: added to the result — in the output Linear's epilogue when that runs on the own bf16 GEMM."""
+        h = self.net[1](self.net[0](x))
+        lin = self.net[2]
+        if residual is not None and isinstance(lin, SalunLinearBF16) and h.dtype == torch.bfloat16 \
+                and residual.dtype == torch.bfloat16:
+            return lin(h, addend=residual)
+        y = lin(h)
+        return y if residual is None else y + residual
 
 
 class BasicTransformerBlock(nn.Module):
@@ -194,9 +211,9 @@ class BasicTransformerBlock(nn.Module):
         return ln(x)
 
     def _forward(self, x, context):
-        x = self.attn1(self._ln(self.norm1, x)) + x
-        x = self.attn2(self._ln(self.norm2, x), context) + x
-        return self.ff(self._ln(self.norm3, x)) + x
+        x = self.attn1(self._ln(self.norm1, x), residual=x)
+        x = self.attn2(self._ln(self.norm2, x), context, residual=x)
+        return self.ff(self._ln(self.norm3, x), residual=x)
 
     def forward(self, x, context=None):
         if self.use_checkpoint and torch.is_grad_enabled():

@@ -113,24 +113,43 @@ def _tokens_nhwc(t: torch.Tensor, C: int) -> torch.Tensor:
     return t.view(1, M // 8, 8, C) if M % 8 == 0 else t.view(1, M, 1, C)
 
 
+# SALUN_LINEAR_GEMM=0: keep the Linear layers on the K11 1x1 convolution kernels (A/B switch); variant pins a K16 tile
+import os as _os
+_USE_K16 = [_os.environ.get("SALUN_LINEAR_GEMM", "1") != "0"]
+_K16_VARIANT = [int(_os.environ.get("SALUN_LINEAR_GEMM_VARIANT", "0"))]
+
+
 class _LinearBF16Fn(torch.autograd.Function):
+    """y = x W^T + b (+ addend) on bf16 tokens.  Forward and input gradient: K16 (csrc/salun_gemm.hip, direct-to-LDS
+    GEMM on the [N, K] / [K, N] weight images) when the feature counts are multiples of 64, else the K11 1x1
+    convolution kernels; weight / bias gradients: K11 backward-weight, added in fp32 into the flat gradient."""
+
     @staticmethod
     def forward(ctx, x, w, bias, mod, addend):
         K, C = w.shape
-        xn = _tokens_nhwc(x, C)
-        an = _tokens_nhwc(addend, K) if addend is not None else None
-        y = ops.conv2d_bf16_forward(xn, mod.packed_weight(), 1, 1, 0, bias=bias, nbias=None, addend=an)
-        ctx.save_for_backward(xn, w)
+        x2 = x.to(torch.bfloat16).contiguous().view(-1, C)
+        M = x2.shape[0]
+        a2 = addend.to(torch.bfloat16).contiguous().view(-1, K) if addend is not None else None
+        k16 = _USE_K16[0] and ops.gemm_bf16_supported(M, K, C)
+        if k16:
+            y = ops.gemm_bf16_nt(x2, mod.packed_weight().view(K, C), bias, a2, _K16_VARIANT[0])
+        else:
+            xn = x2.view(1, M // 8, 8, C) if M % 8 == 0 else x2.view(1, M, 1, C)
+            an = a2.view(1, xn.shape[1], xn.shape[2], K) if a2 is not None else None
+            y = ops.conv2d_bf16_forward(xn, mod.packed_weight(), 1, 1, 0, bias=bias, nbias=None, addend=an)
+        ctx.save_for_backward(x2, w)
         ctx.mod, ctx.has_bias, ctx.x_shape, ctx.x_dtype = mod, bias is not None, tuple(x.shape), x.dtype
         ctx.addend_dtype = addend.dtype if addend is not None else None
         return y.view(*x.shape[:-1], K)
 
     @staticmethod
     def backward(ctx, dy):
-        xn, w = ctx.saved_tensors
+        x2, w = ctx.saved_tensors
         mod = ctx.mod
         K, C = w.shape
-        dyn = _tokens_nhwc(dy, K)
+        M = x2.shape[0]
+        dy2 = dy.to(torch.bfloat16).contiguous().view(M, K)
+        as_img = lambda t, ch: t.view(1, M // 8, 8, ch) if M % 8 == 0 else t.view(1, M, 1, ch)
         dx = dw = db = dadd = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dst = gradsink.sink(w)
@@ -138,13 +157,17 @@ class _LinearBF16Fn(torch.autograd.Function):
             if ctx.has_bias and bdst is None:
                 bdst = torch.zeros(K, dtype=torch.float32, device=w.device)
                 db = bdst
-            got = ops.conv2d_bf16_backward_weight(xn, dyn, (K, C, 1, 1), 1, 0,
+            got = ops.conv2d_bf16_backward_weight(as_img(x2, C), as_img(dy2, K), (K, C, 1, 1), 1, 0,
                                                   out=dst.view(K, C, 1, 1) if dst is not None else None,
                                                   accumulate=True, bias_out=bdst)
             if dst is None:
                 dw = got.view(K, C)
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_bf16_backward_data(dyn, mod.packed_weight(), tuple(xn.shape), 1, 1, 0).view(ctx.x_shape)
+            if _USE_K16[0] and ops.gemm_bf16_supported(M, C, K):
+                dx = ops.gemm_bf16_nt(dy2, mod.packed_weight_t(), None, None, _K16_VARIANT[0]).view(ctx.x_shape)
+            else:
+                dx = ops.conv2d_bf16_backward_data(as_img(dy2, K), mod.packed_weight(), (1,) + tuple(as_img(x2, C).shape[1:]),
+                                                   1, 1, 0).view(ctx.x_shape)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
         if ctx.addend_dtype is not None and ctx.needs_input_grad[4]:
@@ -158,17 +181,34 @@ class SalunLinearBF16(nn.Linear):
 
     _pack = None
     _pack_key = None
+    _pack_t = None
+    _pack_t_key = None
 
-    def packed_weight(self) -> torch.Tensor:
+    def _key(self):
         w = self.weight
         flat = getattr(w, "_salun_flat", None)
-        key = (ops.PARAM_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
+        return (ops.PARAM_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
+
+    def packed_weight(self) -> torch.Tensor:
+        """bf16 image [N, 1, K] (= [N, K]) of the master weights, re-packed once per optimizer step."""
+        w = self.weight
+        key = self._key()
         if self._pack is None or self._pack_key != key or self._pack.device != w.device:
             K, C = w.shape
             self._pack = ops.conv2d_bf16_pack(w.detach().view(K, C, 1, 1),
                                               self._pack if self._pack is not None and self._pack.device == w.device else None)
             self._pack_key = key
         return self._pack
+
+    def packed_weight_t(self) -> torch.Tensor:
+        """bf16 image [K, N] (the transposed weights the input-gradient GEMM reads)."""
+        w = self.weight
+        key = self._key()
+        if self._pack_t is None or self._pack_t_key != key or self._pack_t.device != w.device:
+            self._pack_t = ops.pack_bf16(w.detach(), True,
+                                         self._pack_t if self._pack_t is not None and self._pack_t.device == w.device else None)
+            self._pack_t_key = key
+        return self._pack_t
 
     def forward(self, x, addend=None):
         """`addend` (a tensor of the output's shape, e.g. the residual branch) is added in the kernel's epilogue."""

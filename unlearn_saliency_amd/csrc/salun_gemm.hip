@@ -488,3 +488,266 @@ SALUN_EXPORT int salun_colsum_f32(const float *x, float *out, int64_t M, int N, 
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }
+
+// =====================================================================================================================
+// K16: bf16 GEMM  y[M, N] = x[M, K] . Wp[N, K]^T (+ bias[N]) (+ addend[M, N])  on v_mfma_f32_32x32x16_bf16 — the Linear
+// layers of the Stable-Diffusion transformer blocks in the bf16 configuration (reference: autocast over
+// SD/ldm/modules/attention.py:37-75 GEGLU / FeedForward, :149-200 CrossAttention to_q / to_k / to_v / to_out), which
+// rounds 1-3 left on the library GEMM.  The input gradient dX = dY . W is the same kernel on the transposed weight
+// image WpT[K, N] (both images are packed from the fp32 master weights once per optimizer step).
+//
+// Structure (cdna_hip_programming.md §5): both operand tiles go global -> LDS directly (`global_load_lds_dwordx4`: 16 B
+// per lane, no staging registers, no ds_write pass).  An LDS row is one 64-element (128-byte) k-step of one matrix row;
+// the DMA writes lane-linear, so the bank swizzle is applied to the SOURCE address (lane (row, c') fetches chunk
+// c' ^ ((row >> 1) & 7) of its row) and again on the fragment reads — `ds_read_b128` then touches 16 distinct 16-byte
+// slots per 16-lane group (conflict-free) while every 128-byte global row segment is still read whole.
+// The instruction's A operand is the WEIGHT tile (rows = output features) and B the token tile, so a lane ends up with
+// 4 consecutive output features of one token per accumulator quad: the epilogue stores 8 bytes per lane (bias / residual
+// added in fp32, one rounding) instead of sixteen 2-byte stores.
+// Workgroup = WGM x WGN waves, each a 64-feature x 64-token result tile (2 x 2 MFMA tiles); DB = double-buffered LDS
+// with one barrier per k-step (loads of step s+1 in flight under the MFMAs of step s), else one buffer / two barriers
+// and more workgroups per CU.  Workgroup ids are remapped so that each XCD walks a contiguous run of tiles (token tile
+// fixed, feature tiles consecutive): the token tile is re-read from that XCD's L2.
+// Requirements: K % 64 == 0, N % (64 WGN) == 0, 16-byte aligned pointers; M is arbitrary (rows past M re-read row M-1
+// and are never stored).
+namespace {
+
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char *lds_ptr_t;
+
+struct GbArgs {
+  const uint16_t *x;       // [M][K] bf16
+  const uint16_t *w;       // [N][K] bf16
+  const float *bias;       // [N] fp32 or null
+  const uint16_t *addend;  // [M][N] bf16 or null
+  uint16_t *y;             // [M][N] bf16
+  int M, N, K;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ uint32_t gb_pack2(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float gb_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float gb_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int WGM, int WGN, bool DB>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt(const GbArgs g) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BMt = 64 * WGM, BNt = 64 * WGN;  // token rows, feature rows of the block tile
+  constexpr int ROWS = BMt + BNt;
+  constexpr int STAGE = ROWS * 128;              // bytes: one 64-element k-step of every row
+  constexpr int IPW = ROWS / 8 / NW;             // DMA instructions per wave and k-step (8 rows each)
+  static_assert(ROWS % (8 * NW) == 0, "tile");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wm = wave % WGM, wn = wave / WGM;
+
+  // ---- XCD-aware tile order (bijective remap: XCD x gets a contiguous run of tile indices)
+  const int ntile = g.tiles_m * g.tiles_n;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = ntile >> 3, r = ntile & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BMt, n0 = tn * BNt;
+
+  // ---- per-lane DMA sources: instruction i of this wave moves block rows [8 (wave IPW + i), +8)
+  uint32_t src_off[IPW];  // element offset of this lane's 16 bytes at k-step 0
+  bool src_w[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int rr = 8 * (wave * IPW + i) + (lane >> 3);      // block row
+    const int c = (lane & 7) ^ ((rr >> 1) & 7);             // source chunk for LDS chunk (lane & 7)
+    if (rr < BMt) {
+      int m = m0 + rr;
+      if (m > g.M - 1) m = g.M - 1;
+      src_off[i] = (uint32_t)m * (uint32_t)g.K + c * 8;
+      src_w[i] = false;
+    } else {
+      src_off[i] = (uint32_t)(n0 + rr - BMt) * (uint32_t)g.K + c * 8;
+      src_w[i] = true;
+    }
+  }
+  auto issue = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const uint16_t *p = (src_w[i] ? g.w : g.x) + src_off[i] + ks * 64;
+      lds_ptr_t d = (lds_ptr_t)(lds + buf * STAGE + (wave * IPW + i) * 1024);
+      __builtin_amdgcn_global_load_lds(p, d, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];  // [feature tile][token tile]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+  // fragment reads: row (64-row tile base + 32 t + lo), logical chunk 2 kk + hi -> physical chunk ^ ((row >> 1) & 7);
+  // the tile bases are multiples of 32, so the swizzle term depends on the lane only
+  const int sw = (lo >> 1) & 7;
+  const int x_row = (wm * 64 + lo) * 128;          // token tile region starts at 0
+  const int w_row = (BMt + wn * 64 + lo) * 128;    // feature tile region behind it
+  int ch[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) ch[kk] = ((2 * kk + hi) ^ sw) * 16;
+
+  auto compute = [&](int buf) {
+    const char *base = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const g_bf16x8 w0 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + ch[kk]);
+      const g_bf16x8 w1 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + 32 * 128 + ch[kk]);
+      const g_bf16x8 x0 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + ch[kk]);
+      const g_bf16x8 x1 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + 32 * 128 + ch[kk]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[1][1], 0, 0, 0);
+    }
+  };
+
+  const int nk = g.K >> 6;
+  if (DB) {
+    issue(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of step ks has landed
+      __syncthreads();                     // ... everyone's has, and everyone is done reading the other buffer
+      if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+      compute(ks & 1);
+    }
+  } else {
+    for (int ks = 0; ks < nk; ++ks) {
+      issue(ks, 0);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: D[i = feature][j = token]; lane (j = lo, half hi), register v: i = (v & 3) + 8 (v >> 2) + 4 hi
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int m = m0 + wm * 64 + b * 32 + lo;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * hi;
+        float o0 = acc[a][b][4 * q], o1 = acc[a][b][4 * q + 1], o2 = acc[a][b][4 * q + 2], o3 = acc[a][b][4 * q + 3];
+        if (g.bias) {
+          const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n);
+          o0 += bv.x; o1 += bv.y; o2 += bv.z; o3 += bv.w;
+        }
+        const size_t e = (size_t)m * g.N + n;
+        if (g.addend) {
+          const uint2 av = *reinterpret_cast<const uint2 *>(g.addend + e);
+          o0 += gb_lo(av.x); o1 += gb_hi(av.x); o2 += gb_lo(av.y); o3 += gb_hi(av.y);
+        }
+        *reinterpret_cast<uint2 *>(g.y + e) = make_uint2(gb_pack2(o0, o1), gb_pack2(o2, o3));
+      }
+  }
+}
+
+// fp32 [N][K] -> bf16 [K][N] (the weight image the input-gradient GEMM reads); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void k_pack_bf16_t(const float *__restrict__ w, uint16_t *__restrict__ wt, int N, int K) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + ty + 8 * r, k = k0 + tx;
+    tile[ty + 8 * r][tx] = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = k0 + ty + 8 * r, n = n0 + tx;
+    if (k < K && n < N) wt[(size_t)k * N + n] = __builtin_bit_cast(uint16_t, (__bf16)tile[tx][ty + 8 * r]);
+  }
+}
+__global__ __launch_bounds__(256) void k_pack_bf16(const float *__restrict__ w, uint16_t *__restrict__ wp, int64_t n) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4 *>(w + i);
+      *reinterpret_cast<uint2 *>(wp + i) = make_uint2(gb_pack2(v.x, v.y), gb_pack2(v.z, v.w));
+    } else {
+      for (int64_t j2 = i; j2 < n; ++j2) wp[j2] = __builtin_bit_cast(uint16_t, (__bf16)w[j2]);
+    }
+  }
+}
+
+template <int WGM, int WGN, bool DB>
+int launch_gemm_bf16(const GbArgs &g0, hipStream_t st) {
+  GbArgs g = g0;
+  constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
+  g.tiles_m = (g.M + BMt - 1) / BMt;
+  g.tiles_n = g.N / BNt;
+  const size_t ldsb = (size_t)(DB ? 2 : 1) * (BMt + BNt) * 128;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt<WGM, WGN, DB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_gemm_bf16_nt<WGM, WGN, DB>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+}  // namespace
+
+SALUN_EXPORT int salun_gemm_bf16_supported(int64_t M, int N, int K) {
+  return (M >= 1 && N >= 64 && K >= 64 && N % 64 == 0 && K % 64 == 0 && M * (int64_t)K < (1ll << 31) &&
+          (int64_t)N * K < (1ll << 31)) ? 1 : 0;
+}
+
+// variant: 0 = choose; 1 = 128 tokens x 128 features double-buffered, 2 = same single-buffered, 3 = 256 tokens x 64
+// features double-buffered, 4 = same single-buffered (A/B measurements: tools/gemmbench_bf16.py)
+SALUN_EXPORT int salun_gemm_bf16_nt(const void *x, const void *w, const float *bias, const void *addend, void *y, int64_t M,
+                                    int N, int K, int variant, salun_stream_t stream) {
+  if (!salun_gemm_bf16_supported(M, N, K) || !x || !w || !y) return SALUN_EINVAL;
+  if (!salun_aligned16(x) || !salun_aligned16(w) || !salun_aligned16(y) || (bias && !salun_aligned16(bias)) ||
+      (addend && !salun_aligned16(addend)))
+    return SALUN_EINVAL;
+  GbArgs g;
+  g.x = static_cast<const uint16_t *>(x); g.w = static_cast<const uint16_t *>(w); g.bias = bias;
+  g.addend = static_cast<const uint16_t *>(addend); g.y = static_cast<uint16_t *>(y);
+  g.M = (int)M; g.N = N; g.K = K; g.tiles_m = g.tiles_n = 0;
+  hipStream_t st = salun_hip_stream(stream);
+  if (variant == 0) variant = (N % 128 == 0) ? 1 : 3;
+  if ((variant == 1 || variant == 2) && N % 128 != 0) return SALUN_EINVAL;
+  switch (variant) {
+    case 1: return launch_gemm_bf16<2, 2, true>(g, st);
+    case 2: return launch_gemm_bf16<2, 2, false>(g, st);
+    case 3: return launch_gemm_bf16<4, 1, true>(g, st);
+    case 4: return launch_gemm_bf16<4, 1, false>(g, st);
+    default: return SALUN_EINVAL;
+  }
+}
+
+SALUN_EXPORT int salun_pack_bf16(const float *w, void *wp, int N, int K, int transposed, salun_stream_t stream) {
+  if (N < 1 || K < 1 || !w || !wp) return SALUN_EINVAL;
+  hipStream_t st = salun_hip_stream(stream);
+  if (transposed) {
+    hipLaunchKernelGGL(k_pack_bf16_t, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, w, static_cast<uint16_t *>(wp), N, K);
+  } else {
+    if (!salun_aligned16(w) || !salun_aligned16(wp)) return SALUN_EINVAL;
+    const int64_t n = (int64_t)N * K;
+    hipLaunchKernelGGL(k_pack_bf16, dim3(salun_grid_for(n, 1024)), dim3(256), 0, st, w, static_cast<uint16_t *>(wp), n);
+  }
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}

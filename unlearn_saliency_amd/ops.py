@@ -464,6 +464,36 @@ def conv2d_bf16_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stri
     return dw
 
 
+# ----------------------------------------------------------------------------- K16
+def gemm_bf16_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.lib().salun_gemm_bf16_supported(c_int64(M), int(N), int(K)))
+
+
+def gemm_bf16_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 addend: Optional[torch.Tensor] = None, variant: int = 0) -> torch.Tensor:
+    """y[M, N] = x[M, K] . w[N, K]^T (+ bias fp32 [N]) (+ addend bf16 [M, N]); x, w contiguous bf16 (csrc/salun_gemm.hip)."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().salun_gemm_bf16_nt(_dev(x, torch.bfloat16, "x"), _dev(w, torch.bfloat16, "w"),
+                                        _dev(bias, torch.float32, "bias", True), _dev(addend, torch.bfloat16, "addend", True),
+                                        c_void_p(y.data_ptr()), c_int64(M), N, K, int(variant), _stream()),
+          "salun_gemm_bf16_nt")
+    return y
+
+
+def pack_bf16(w: torch.Tensor, transposed: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [N, K] master weights -> bf16 [N, K] (or [K, N] with `transposed`): the images gemm_bf16_nt reads."""
+    N, K = w.shape
+    PACK_CALLS[0] += 1
+    if out is None:
+        out = torch.empty((K, N) if transposed else (N, K), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().salun_pack_bf16(_dev(w, torch.float32, "w"), _dev(out, torch.bfloat16, "wp"), N, K, int(bool(transposed)),
+                                     _stream()), "salun_pack_bf16")
+    return out
+
+
 # ----------------------------------------------------------------------------- K12
 def gn_bf16_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool):
     """x [N, H, W, C] bf16 contiguous -> (y, mr, ab): y = [silu](GroupNorm(x)); mr / ab feed gn_bf16_backward."""

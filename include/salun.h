@@ -180,6 +180,18 @@ int salun_masked_adam_step(float *p /*dev*/, const float *g /*dev*/, float *m1 /
                            double gscale, double lr, double b1, double b2, double eps,
                            double wd, int step, int64_t n, salun_stream_t stream);
 
+/* The same step with its step-dependent scalars taken from DEVICE memory — for whole-step HIP graphs, which replay
+ * identical kernel arguments every step (the host cannot pass t):
+ *   salun_adam_coefficients: ++(*step) on the stream, then coef = { sqrt(1 - b2^t), -lr / (1 - b1^t) } in the same
+ *     double arithmetic as salun_masked_adam_step;
+ *   salun_masked_adam_step_coef: salun_masked_adam_step reading those two floats instead of (lr, step). */
+int salun_adam_coefficients(int64_t *step /*dev*/, double lr, double b1, double b2, float *coef /*dev [2]*/,
+                            salun_stream_t stream);
+int salun_masked_adam_step_coef(float *p /*dev*/, const float *g /*dev*/, float *m1 /*dev*/, float *v /*dev*/,
+                                const uint8_t *mask /*dev or NULL*/, const float *sqnorm /*dev or NULL*/,
+                                double max_norm, double gscale, const float *coef /*dev [2]*/, double b1, double b2,
+                                double eps, double wd, int64_t n, salun_stream_t stream);
+
 /* ------------------------------------------------------------------ K6 --
  * Forward diffusion sample:  xt = x0*sqrt_ab[t[b]] + e*sqrt_1mab[t[b]]
  * Replaces  DDPM/functions/losses.py:31-32, runners/diffusion.py:558-559,973-974.

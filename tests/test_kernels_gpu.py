@@ -443,6 +443,26 @@ def test_masked_adam_bit_exact(ops, oracle_mod, n, wd, masked):
     assert np.array_equal(bits(dv.cpu().numpy()), bits(v))
 
 
+def test_masked_adam_with_a_device_resident_step_counter(ops, oracle_mod):
+    """salun_adam_coefficients + salun_masked_adam_step_coef (whole-step HIP graphs: the host cannot pass t) against the
+    host-scalar entry: bit-identical parameters and moments over four steps."""
+    n = 100_003
+    p0, g = oracle_mod.fill_normal(n, 1, 0, 0.05), oracle_mod.fill_normal(n, 2, 0, 1e-2)
+    mask = (oracle_mod.fill_u8(n, 3) & 1).astype(np.uint8)
+    a = [dev(p0.copy()), dev(np.zeros(n, np.float32)), dev(np.zeros(n, np.float32))]
+    b = [dev(p0.copy()), dev(np.zeros(n, np.float32)), dev(np.zeros(n, np.float32))]
+    dg, dm = dev(g), dev(mask)
+    step_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+    coef = torch.zeros(2, dtype=torch.float32, device="cuda")
+    for step in range(1, 5):
+        ops.masked_adam_step(a[0], dg, a[1], a[2], dm, 1e-4, 0.9, 0.999, 1e-8, 0.0, step)
+        ops.adam_coefficients(step_dev, 1e-4, 0.9, 0.999, coef)
+        ops.masked_adam_step_coef(b[0], dg, b[1], b[2], dm, coef, 0.9, 0.999, 1e-8, 0.0)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), step
+    assert int(step_dev.item()) == 4
+
+
 def test_masked_adam_device_clip_and_frozen_weights(ops, oracle_mod):
     """clip -> mask -> Adam order (runners/diffusion.py:582-593); masked-out weights never move."""
     n = 300_007

@@ -92,6 +92,7 @@ class ResBlock(nn.Module):
         super().__init__()
         out_channels = out_channels or channels
         self.use_checkpoint = use_checkpoint
+        self.preserve_rng = dropout > 0  # no random draw inside the block otherwise: nothing to replay on recompute
         self.in_layers = nn.Sequential(GroupNorm32(32, channels), nn.SiLU(), nn.Conv2d(channels, out_channels, 3, padding=1))
         self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, out_channels))
         self.out_layers = nn.Sequential(GroupNorm32(32, out_channels), nn.SiLU(), nn.Dropout(p=dropout),
@@ -114,7 +115,7 @@ class ResBlock(nn.Module):
 
     def forward(self, x, emb):
         if self.use_checkpoint and torch.is_grad_enabled():
-            return _ckpt(self._forward, x, emb, use_reentrant=False)
+            return _ckpt(self._forward, x, emb, use_reentrant=False, preserve_rng_state=self.preserve_rng)
         return self._forward(x, emb)
 
 
@@ -201,6 +202,7 @@ class BasicTransformerBlock(nn.Module):
         self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head, dropout)
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
         self.use_checkpoint = use_checkpoint
+        self.preserve_rng = dropout > 0
 
     @staticmethod
     def _ln(ln, x):
@@ -217,7 +219,7 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, context=None):
         if self.use_checkpoint and torch.is_grad_enabled():
-            return _ckpt(self._forward, x, context, use_reentrant=False)
+            return _ckpt(self._forward, x, context, use_reentrant=False, preserve_rng_state=self.preserve_rng)
         return self._forward(x, context)
 
 

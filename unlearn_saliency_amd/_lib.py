@@ -66,6 +66,10 @@ SIGNATURES = {
     "salun_masked_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                        c_double, c_double, c_double, c_double, c_double, c_double, c_int, c_int64,
                                        c_void_p]),
+    "salun_adam_coefficients": (c_int, [c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
+    "salun_masked_adam_step_coef": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
+                                            c_double, c_void_p, c_double, c_double, c_double, c_double, c_int64,
+                                            c_void_p]),
     "salun_qsample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                               c_void_p]),
     "salun_sqerr_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -241,6 +241,7 @@ struct AdamArgs {
   float max_norm, gscale;
   float b1, omb1, b2, omb2, eps, wd;
   float bc2_sqrt, neg_step_size;
+  const float *coef;  // optional device pair {sqrt(1 - b2^t), -lr / (1 - b1^t)}: replaces the two host values above
   int64_t n;
 };
 
@@ -255,9 +256,23 @@ __device__ __forceinline__ void adam_elem(float &p, float g, float &m1, float &v
   p = p + (a.neg_step_size * (m1 / den));
 }
 
+// step-dependent scalars of Adam computed ON THE DEVICE from a device-resident step counter (a captured HIP graph
+// replays the same kernel arguments every step: the host cannot pass t).  Same double arithmetic as the host path.
+__global__ void k_adam_coefficients(long long *step, double lr, double b1, double b2, float *coef) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow(b1, (double)t);
+    const double bc2 = 1.0 - pow(b2, (double)t);
+    coef[0] = (float)sqrt(bc2);
+    coef[1] = (float)(-(lr / bc1));
+  }
+}
+
 template <bool HAS_MASK, bool HAS_WD, bool VEC>
 __global__ __launch_bounds__(SALUN_BLOCK) void k_masked_adam(AdamArgs a) {
   const float s = a.sqnorm ? salun_clip_coef(*a.sqnorm, a.max_norm) : a.gscale;
+  if (a.coef) { a.bc2_sqrt = a.coef[0]; a.neg_step_size = a.coef[1]; }
   if (VEC) {
     const int64_t nvec = a.n >> 2;
     const int64_t ntile = (nvec + TILE_VEC - 1) / TILE_VEC;
@@ -441,16 +456,45 @@ SALUN_EXPORT int salun_grad_sqnorm(const float *g, int64_t n, float *out, void *
   return SALUN_OK;
 }
 
+static int masked_adam_impl(float *p, const float *g, float *m1, float *v, const uint8_t *mask, const float *sqnorm,
+                            double max_norm, double gscale, double lr, double b1, double b2, double eps, double wd,
+                            int step, const float *coef, int64_t n, salun_stream_t stream);
+
 SALUN_EXPORT int salun_masked_adam_step(float *p, const float *g, float *m1, float *v, const uint8_t *mask,
                                         const float *sqnorm, double max_norm, double gscale, double lr,
                                         double b1, double b2, double eps, double wd, int step, int64_t n,
                                         salun_stream_t stream) {
+  if (step < 1) return SALUN_EINVAL;
+  return masked_adam_impl(p, g, m1, v, mask, sqnorm, max_norm, gscale, lr, b1, b2, eps, wd, step, nullptr, n, stream);
+}
+
+SALUN_EXPORT int salun_adam_coefficients(int64_t *step, double lr, double b1, double b2, float *coef,
+                                         salun_stream_t stream) {
+  if (!step || !coef) return SALUN_EINVAL;
+  hipLaunchKernelGGL(k_adam_coefficients, dim3(1), dim3(64), 0, salun_hip_stream(stream),
+                     reinterpret_cast<long long *>(step), lr, b1, b2, coef);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
+SALUN_EXPORT int salun_masked_adam_step_coef(float *p, const float *g, float *m1, float *v, const uint8_t *mask,
+                                             const float *sqnorm, double max_norm, double gscale, const float *coef,
+                                             double b1, double b2, double eps, double wd, int64_t n,
+                                             salun_stream_t stream) {
+  if (!coef) return SALUN_EINVAL;
+  return masked_adam_impl(p, g, m1, v, mask, sqnorm, max_norm, gscale, 0.0, b1, b2, eps, wd, 1, coef, n, stream);
+}
+
+static int masked_adam_impl(float *p, const float *g, float *m1, float *v, const uint8_t *mask, const float *sqnorm,
+                            double max_norm, double gscale, double lr, double b1, double b2, double eps, double wd,
+                            int step, const float *coef, int64_t n, salun_stream_t stream) {
   if (n < 0 || step < 1 || (n > 0 && (!p || !g || !m1 || !v))) return SALUN_EINVAL;
   if (n == 0) return SALUN_OK;
   // Python-scalar arithmetic of torch.optim.adam._single_tensor_adam, in double.
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
   AdamArgs a;
+  a.coef = coef;
   a.p = p; a.g = g; a.m1 = m1; a.v = v; a.mask = mask; a.sqnorm = sqnorm;
   a.max_norm = (float)max_norm; a.gscale = (float)gscale;
   a.b1 = (float)b1; a.omb1 = (float)(1.0 - b1); a.b2 = (float)b2; a.omb2 = (float)(1.0 - b2);

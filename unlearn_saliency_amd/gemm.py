@@ -296,7 +296,12 @@ def _bmm(c: torch.Tensor, ci: int, cj: int, a: torch.Tensor, ai: int, ak: int, b
 
 def _dense_like(t: torch.Tensor) -> torch.Tensor:
     """An uninitialised tensor with t's shape AND strides when t is dense (so outputs land in the caller's layout)."""
-    if t.is_non_overlapping_and_dense():
+    dims = sorted((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1)
+    expect, dense = 1, True
+    for st, sz in dims:  # non-overlapping and dense: sorted by stride, each stride is the extent of everything below it
+        dense = dense and st == expect
+        expect *= sz
+    if dense:
         return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
     return torch.empty(t.shape, dtype=t.dtype, device=t.device)
 

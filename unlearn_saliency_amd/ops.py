@@ -200,6 +200,27 @@ def masked_adam_step(p: torch.Tensor, g: torch.Tensor, m1: torch.Tensor, v: torc
                                             _stream()), "salun_masked_adam_step")
 
 
+def adam_coefficients(step_dev: torch.Tensor, lr: float, beta1: float, beta2: float, coef: torch.Tensor) -> None:
+    """++step_dev (int64[1], device) and coef <- {sqrt(1 - b2^t), -lr / (1 - b1^t)} on the stream."""
+    check(_lib.lib().salun_adam_coefficients(_dev(step_dev, torch.int64, "step"), c_double(lr), c_double(beta1),
+                                             c_double(beta2), _dev(coef, torch.float32, "coef"), _stream()),
+          "salun_adam_coefficients")
+
+
+def masked_adam_step_coef(p, g, m1, v, mask, coef, beta1, beta2, eps, weight_decay, sqnorm=None, max_norm=1.0,
+                          gscale=1.0) -> None:
+    """masked_adam_step with the step-dependent scalars read from device memory (whole-step HIP graphs)."""
+    n = p.numel()
+    PARAM_EPOCH[0] += 1
+    check(_lib.lib().salun_masked_adam_step_coef(_dev(p, torch.float32, "p"), _dev(g, torch.float32, "g"),
+                                                 _dev(m1, torch.float32, "exp_avg"), _dev(v, torch.float32, "exp_avg_sq"),
+                                                 _dev(mask, torch.uint8, "mask", True),
+                                                 _dev(sqnorm, torch.float32, "sqnorm", True), c_double(max_norm),
+                                                 c_double(gscale), _dev(coef, torch.float32, "coef"), c_double(beta1),
+                                                 c_double(beta2), c_double(eps), c_double(weight_decay), c_int64(n),
+                                                 _stream()), "salun_masked_adam_step_coef")
+
+
 # ----------------------------------------------------------------------------- K6
 def qsample(x0: torch.Tensor, e: torch.Tensor, sqrt_ab: torch.Tensor, sqrt_1mab: torch.Tensor,
             t: torch.Tensor) -> torch.Tensor:

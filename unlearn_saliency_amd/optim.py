@@ -162,6 +162,16 @@ class FusedMaskedAdam(_FlatOptimizer):
         self.exp_avg_sq = arena.new_like()
         self.grad_clip = grad_clip
         self._sqnorm = torch.zeros(1, dtype=torch.float32, device=arena.device)
+        self._step_dev = None  # device-resident step counter (use_device_step): whole-step HIP graphs
+        self._coef = None
+
+    def use_device_step(self) -> None:
+        """Keep Adam's step count (hence its bias corrections) on the device: a captured HIP graph replays the same
+        kernel arguments every step, so the host cannot pass t.  `steps` on the host keeps counting `step()` calls; a
+        graph replay advances only the device counter (graphs.StepGraph adds the host increment)."""
+        if self._step_dev is None:
+            self._step_dev = torch.tensor([self.steps], dtype=torch.int64, device=self.arena.device)
+            self._coef = torch.zeros(2, dtype=torch.float32, device=self.arena.device)
 
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
         """Arms clipping for the next step() and returns the squared norm (device tensor, no sync).
@@ -178,6 +188,12 @@ class FusedMaskedAdam(_FlatOptimizer):
         sq = None
         if self.grad_clip is not None:
             sq = ops.grad_sqnorm(self.arena.grads, self._sqnorm)
+        if self._step_dev is not None:
+            ops.adam_coefficients(self._step_dev, g["lr"], g["betas"][0], g["betas"][1], self._coef)
+            ops.masked_adam_step_coef(self.arena.params, self.arena.grads, self.exp_avg, self.exp_avg_sq, self.mask_u8,
+                                      self._coef, g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], sqnorm=sq,
+                                      max_norm=self.grad_clip if self.grad_clip is not None else 1.0)
+            return loss
         ops.masked_adam_step(self.arena.params, self.arena.grads, self.exp_avg, self.exp_avg_sq, self.mask_u8,
                              g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.steps,
                              sqnorm=sq, max_norm=self.grad_clip if self.grad_clip is not None else 1.0)

@@ -120,7 +120,7 @@ def test_grouped_linear_equals_separate_layers():
     worst = max(worst, rel(x.grad, xr.grad))
     for i, (l, (w, b)) in enumerate(zip(layers, wr)):
         if gs[i] is None:
-            assert l.weight.grad is None
+            assert l.weight.grad is None or float(l.weight.grad.abs().max()) == 0
             continue
         worst = max(worst, rel(l.weight.grad, w.grad), rel(l.bias.grad, b.grad))
     log("grouped_linear 22 x (1024 -> 128|256), batch 128", worst)
@@ -203,12 +203,15 @@ def test_ddpm_unet_gradients_with_own_gemm_on_vs_off():
     (l1, g1, arena), (l0, g0, _) = outs
     assert abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
     worst = 0.0
+    # a key bias shifts every score of a query row by the same amount: softmax does not see it, its true gradient is 0
+    # and both routes deliver round-off (~1e-8 next to gradients of ~1e-1) — scales are floored at 1e-6 of the largest
+    floor = 1e-6 * float(g0.abs().max())
     for name, off, k in zip(arena.names, arena.offsets, arena.numels):
         a, b_ = g1[off:off + k], g0[off:off + k]
-        scale = float(b_.abs().max())
-        if scale == 0:
-            assert float(a.abs().max()) == 0, name
-            continue
-        worst = max(worst, float((a - b_).abs().max()) / scale)
+        scale = max(float(b_.abs().max()), floor)
+        err = float((a - b_).abs().max()) / scale
+        if err > 2e-5:
+            print(f"  {name}: {err:.3e} (scale {scale:.3e})")
+        worst = max(worst, err)
     log("DDPM reduced U-Net, own GEMM on vs off: worst parameter gradient", worst)
     assert worst <= 2e-5, worst

@@ -94,6 +94,7 @@ class _ConvFn(torch.autograd.Function):
                 else:
                     x.record_stream(side)
                     dy.record_stream(side)
+                    resblock.hold_until_join(dy)  # autograd must not accumulate into dy in place while the side stream reads it
                     resblock._join_at_end_of_backward(dy.device)
             if not overlap:
                 dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad, out=dst, accumulate=True) if ctx.native else None
@@ -157,9 +158,12 @@ def use_salun_convs(model: nn.Module) -> int:
     if own_gemm and _OWN_GEMM[0]:
         # diffusion U-Nets: attention and every Linear layer on this package's fp32 MFMA GEMM (K15, gemm.py) as well
         from .gemm import use_salun_linears
+        parts = os.environ.get("SALUN_OWN_GEMM_PARTS", "linear,grouped,attn").split(",")  # A/B / debugging
         for m in own_gemm:
-            m.own_gemm = True
-        use_salun_linears(model)
+            is_attn = hasattr(m, "proj_out") or hasattr(m, "to_q")
+            m.own_gemm = ("attn" in parts) if is_attn else ("grouped" in parts)
+        if "linear" in parts:
+            use_salun_linears(model)
     owners = {id(m.conv) for m in model.modules() if getattr(m, "use_mfma", False) and hasattr(m, "conv")}
     for mod in model.modules():
         if type(mod) is nn.Conv2d and _eligible(mod) and id(mod) not in owners:

@@ -219,6 +219,7 @@ class _GroupedLinear(torch.autograd.Function):
         ctx.save_for_backward(x2, *ws)
         ctx.biases = bs
         ctx.G = G
+        ctx.set_materialize_grads(False)  # a projection whose block saw no gradient arrives as None, not as zeros
         return tuple(outs)
 
     @staticmethod

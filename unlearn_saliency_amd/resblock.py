@@ -52,6 +52,7 @@ def reset_join_state() -> None:
     """Forget a pending end-of-backward join (only needed after a backward pass was aborted by an exception) and make
     the current streams wait for whatever the side streams still have in flight."""
     _join_queued.clear()
+    _held.clear()
     for dev, side in _side_streams.items():
         torch.cuda.current_stream(dev).wait_stream(side)
 _side_streams: dict = {}
@@ -65,6 +66,33 @@ def _side_stream(device: torch.device) -> "torch.cuda.Stream":
 
 
 _join_queued: set = set()
+# Gradient tensors a side-stream kernel is still reading.  autograd OWNS a gradient buffer once every node it was handed
+# to has returned, and accumulates further contributions into it IN PLACE when nobody else holds it
+# (InputBuffer::add: `old.add_(new)` if use_count == 1) — on the main stream, while the side stream may still be reading
+# it: `record_stream` guards against reuse after free, not against that write.  A held reference makes the engine
+# accumulate out of place.  Found in round 4 (the first AttnBlock's proj_out weight gradient changed from run to run
+# once the attention's backward became short enough for the residual's accumulation to overtake the 1x1 backward-weight).
+_held: dict = {}
+
+
+def hold_until_join(t: torch.Tensor) -> None:
+    """Keep `t` referenced until the side stream has passed the kernels enqueued on it so far (an event recorded there
+    now has completed), at the latest until the end-of-backward join.  Inside a stream capture events cannot be queried:
+    the reference simply lives until the join."""
+    lst = _held.setdefault(t.device, [])
+    if torch.cuda.is_current_stream_capturing():
+        lst.append((None, t))
+        return
+    ev = torch.cuda.Event()
+    ev.record(_side_stream(t.device))
+    lst.append((ev, t))
+    while lst and lst[0][0] is not None and lst[0][0].query():
+        lst.pop(0)
+
+
+def release_held(device) -> None:
+    """After the main stream has been made to wait for the side stream: nothing is being read there any more."""
+    _held.pop(device, None)
 
 
 def _join_at_end_of_backward(device: torch.device) -> None:
@@ -80,6 +108,7 @@ def _join_at_end_of_backward(device: torch.device) -> None:
     def _join():
         _join_queued.discard(device)
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+        _held.pop(device, None)
 
     torch.autograd.Variable._execution_engine.queue_callback(_join)
 
@@ -141,6 +170,7 @@ class _BasicBlockFn(torch.autograd.Function):
                     dw = ops.conv2d_backward_weight(xin, dy, w.shape, stride, pad, out=dst, accumulate=True)
                 for t in (xin, dy):  # freed when this backward returns: keep the memory until the side stream is done
                     t.record_stream(side)
+                hold_until_join(dy)  # ... and keep autograd from accumulating into it in place meanwhile
                 if dst is None and dw is not None:
                     dw.record_stream(main)
             if dst is not None:
@@ -166,6 +196,7 @@ class _BasicBlockFn(torch.autograd.Function):
                 # data parallel: gradient-arrival hooks may start an all-reduce right after this node; autograd
                 # route: AccumulateGrad consumes the returned tensors on the main stream -> join now
                 main.wait_stream(side)
+                release_held(dout.device)
             else:
                 _join_at_end_of_backward(dout.device)
         return dx, None, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd
@@ -289,6 +320,7 @@ class _DiffusionResnetBlockFn(torch.autograd.Function):
                     dw = ops.conv2d_backward_weight(xin, dy, w.shape, 1, pad, out=dst, accumulate=True)
                 for t in (xin, dy):
                     t.record_stream(side)
+                hold_until_join(dy)
                 if dst is None and dw is not None:
                     dw.record_stream(main)
             if dst is not None:
@@ -351,6 +383,7 @@ class _DiffusionResnetBlockFn(torch.autograd.Function):
         if side is not None:
             if sdist.collectives_on() or returned:
                 main.wait_stream(side)
+                release_held(dout.device)
             else:
                 _join_at_end_of_backward(dout.device)
         if not ctx.needs_input_grad[0]:

@@ -105,3 +105,47 @@ def test_sd_v1_bf16_full_size_unlearn_step():
     assert sconv.library_conv_calls() == 0, sconv.LIBRARY_CONV_CALLS
     assert all(p.dtype == torch.float32 for p in model.model.diffusion_model.parameters())  # fp32 master weights
     _check_masked_update(arena, opt, mask, theta0)
+
+
+def test_side_stream_backward_weight_never_changes_a_gradient_bit():
+    """Full-size CFG-DDPM U-Net, batch 128: every parameter gradient with backward-weight on the side stream equals,
+    bit for bit and run after run, the single-stream result.  Round 4 found the one way it could differ: autograd
+    accumulates the residual's second contribution INTO the gradient buffer (in place, main stream) that the first
+    AttnBlock's proj_out backward-weight kernel was still reading on the side stream — visible once the own fp32
+    attention made that block's backward short (resblock.hold_until_join)."""
+    from unlearn_saliency_amd import resblock
+    from unlearn_saliency_amd.conv import use_salun_convs
+    from unlearn_saliency_amd.DDPM.functions import load_config
+    from unlearn_saliency_amd.DDPM.functions.losses import loss_registry_conditional
+    from unlearn_saliency_amd.DDPM.models.diffusion import Conditional_Model
+    from unlearn_saliency_amd.flat import arena_of
+    cfg = load_config(os.path.join(ROOT, "unlearn_saliency_amd", "DDPM", "configs", "cifar10_saliency_unlearn.yml"))
+    torch.manual_seed(0)
+    model = Conditional_Model(cfg).cuda().train()
+    assert use_salun_convs(model) > 0 and model.own_gemm
+    arena = arena_of(model)
+    x = torch.rand(128, 3, 32, 32, device="cuda") * 2 - 1
+    c = torch.randint(0, 10, (128,), device="cuda")
+    e, t = torch.randn_like(x), torch.randint(0, 1000, (128,), device="cuda")
+    b = torch.linspace(1e-4, 0.02, 1000, device="cuda")
+
+    def grads(overlap):
+        prev = resblock.OVERLAP_WGRAD
+        resblock.OVERLAP_WGRAD = overlap
+        try:
+            torch.manual_seed(5)  # label drop
+            from unlearn_saliency_amd import draws
+            draws.set_state((5, 1, 0))  # dropout keys
+            arena.zero_grad()
+            loss_registry_conditional["simple"](model, x, t, c, e, b).backward()
+            torch.cuda.synchronize()
+        finally:
+            resblock.OVERLAP_WGRAD = prev
+        return arena.grads.clone()
+
+    ref = grads(False)
+    assert torch.equal(grads(False), ref)
+    for rep in range(6):
+        g = grads(True)
+        bad = [n for n, o, k in zip(arena.names, arena.offsets, arena.numels) if not torch.equal(g[o:o + k], ref[o:o + k])]
+        assert not bad, (rep, bad[:5])

@@ -39,8 +39,10 @@ def main(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole unlearning step into a HIP graph (graphs.StepGraph) and replay it: one host "
                          "call per step instead of ~15,000 launches")
-    ap.add_argument("--own_linear", action="store_true",
-                    help="A/B: run the transformer blocks' Linear layers on the K11 1x1 kernels instead of the library GEMM")
+    ap.add_argument("--own_linear", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--library_linear", action="store_true",
+                    help="A/B: leave the transformer blocks' Linear layers on the library GEMM (hipBLASLt under autocast) "
+                         "instead of K16 (forward / input gradient) + K11 (weight gradient)")
     a = ap.parse_args(argv)
     from unlearn_saliency_amd import dist as sdist
     from unlearn_saliency_amd import ops
@@ -67,7 +69,7 @@ def main(argv=None):
     elif not a.library_conv:
         from unlearn_saliency_amd.conv_bf16 import use_salun_convs_bf16, use_salun_linears_bf16
         n_salun = use_salun_convs_bf16(model)
-        if a.own_linear:  # A/B: the transformer blocks' Linear layers on the K11 1x1 kernels (slower: see ldm_lite.py)
+        if not a.library_linear:  # the transformer blocks' Linear layers on K16 / K11 (conv_bf16.SalunLinearBF16)
             n_linear = use_salun_linears_bf16(model)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0

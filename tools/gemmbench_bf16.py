@@ -21,6 +21,9 @@ def timeit(fn, reps):
     return best * 1e3  # us
 
 
+VARS = (1, 2, 3, 7, 8, 9, 10)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
@@ -30,7 +33,7 @@ def main():
     for M, d in ((32768, 320), (8192, 640), (2048, 1280), (512, 1280)):
         shapes += [(M, d, d), (M, 8 * d, d), (M, d, 4 * d)]
     shapes += [(616, 320, 768), (616, 1280, 768)]
-    print(f"{'M':>6} {'N':>6} {'K':>5} | {'lib us':>8} {'TF':>6} | " + " ".join(f"{'v%d us' % v:>8} {'TF':>6}" for v in (1, 2, 3, 4))
+    print(f"{'M':>6} {'N':>6} {'K':>5} | {'lib us':>8} {'TF':>6} | " + " ".join(f"{'v%d us' % v:>8} {'TF':>6}" for v in VARS)
           + f" | {'K11 us':>8} {'TF':>6}")
     tot = {"lib": 0.0, "best": 0.0, "k11": 0.0}
     for M, N, K in shapes:
@@ -41,8 +44,8 @@ def main():
         t_lib = timeit(lambda: torch.nn.functional.linear(x, w, bias.bfloat16()), a.reps)
         row = f"{M:>6} {N:>6} {K:>5} | {t_lib:8.1f} {fl / t_lib / 1e6:6.0f} | "
         best = 1e9
-        for v in (1, 2, 3, 4):
-            if v in (1, 2) and N % 128:
+        for v in VARS:
+            if v in (1, 2, 5, 7, 8, 10) and N % 128:
                 row += f"{'-':>8} {'-':>6} "
                 continue
             t = timeit(lambda: ops.gemm_bf16_nt(x, w, bias, None, v), a.reps)

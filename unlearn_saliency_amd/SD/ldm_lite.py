@@ -65,11 +65,13 @@ class LatentDiffusionLite(nn.Module):
         bf16 configuration, fp32 NCHW (conv.py, K8) otherwise.  Returns the number of modules switched."""
         if self.bf16:
             from ..conv_bf16 import use_salun_convs_bf16, use_salun_linears_bf16
-            # The transformer blocks' Linear layers CAN run on the K11 1x1 kernels (conv_bf16.SalunLinearBF16: cached
-            # packed weights, fp32 gradient accumulation in the kernel, no casts / AccumulateGrad launches), but the
-            # library GEMM is 1.5-2.3x faster in the forward at these shapes (620-670 vs 265-450 TFLOP/s,
-            # profiles/r03_linearbench_bf16.txt) and the whole step loses 7 % (4.38 vs 4.71 steps/s) — opt-in only.
-            if getattr(self, "mfma_linears", False):
+            # The transformer blocks' Linear layers run on K16 (csrc/salun_gemm.hip: direct-to-LDS bf16 GEMM, forward and
+            # input gradient, bias / residual in the epilogue) and K11 (weight gradient, added in fp32 into the flat
+            # gradient): cached bf16 weight images instead of a cast per forward / recompute / backward, no
+            # AccumulateGrad launches.  Round 3 had them on the K11 1x1 kernels alone and lost 7 % of the step to the
+            # library GEMM; K16 is at the library's speed on these shapes (profiles/r04_gemmbench_bf16.txt) and the step
+            # gains 3 % (194 vs 200 ms).  `mfma_linears = False` keeps them on the library (A/B).
+            if getattr(self, "mfma_linears", True):
                 self.n_mfma_linears = use_salun_linears_bf16(self.model.diffusion_model)
             return use_salun_convs_bf16(self.model.diffusion_model)
         from ..conv import use_salun_convs

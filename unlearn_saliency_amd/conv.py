@@ -70,7 +70,9 @@ class _ConvFn(torch.autograd.Function):
             ctx.native = True
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, bias is not None
-        ctx.bias_param = bias  # only looked at for its .grad destination (gradsink), never read as a value
+        # the parameter OBJECTS, only looked at for their .grad destinations (gradsink), never read as values: under
+        # activation checkpointing `saved_tensors` hands back detached aliases, which are not the nn.Parameters any more
+        ctx.bias_param, ctx.weight_param = bias, w
         return y
 
     @staticmethod
@@ -80,7 +82,7 @@ class _ConvFn(torch.autograd.Function):
         stride, pad = ctx.stride, ctx.pad
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
-            dst = gradsink.sink(w) if ctx.native else None
+            dst = gradsink.sink(ctx.weight_param) if ctx.native else None
             # the weight gradient goes straight into .grad (gradsink): nothing on the main stream consumes it before
             # the end of the backward pass, so it can run on the side stream next to backward-data (resblock.py)
             overlap = (dst is not None and resblock.OVERLAP_WGRAD and not sdist.collectives_on())

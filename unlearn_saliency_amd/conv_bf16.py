@@ -49,7 +49,7 @@ class _ConvBF16Fn(torch.autograd.Function):
         dyn = _nhwc(dy)
         dx = dw = db = dnb = dadd = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dst = gradsink.sink(w)
+            dst = gradsink.sink(mod.weight)  # the Parameter itself: `w` from saved_tensors is a detached alias under checkpointing
             # the kernel has ONE accumulate flag for dw and db: without a weight sink it overwrites both outputs, so
             # the bias gradient must not target bias.grad then (it would be overwritten, not accumulated) — it goes
             # through autograd like dw; with a weight sink but no bias sink, db accumulates into fresh zeros
@@ -152,7 +152,7 @@ class _LinearBF16Fn(torch.autograd.Function):
         as_img = lambda t, ch: t.view(1, M // 8, 8, ch) if M % 8 == 0 else t.view(1, M, 1, ch)
         dx = dw = db = dadd = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dst = gradsink.sink(w)
+            dst = gradsink.sink(mod.weight)
             bdst = gradsink.sink(mod.bias) if (ctx.has_bias and dst is not None) else None
             if ctx.has_bias and bdst is None:
                 bdst = torch.zeros(K, dtype=torch.float32, device=w.device)

@@ -661,6 +661,325 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt(const GbArgs g)
   }
 }
 
+// The same tile machinery as a PERSISTENT kernel: a workgroup walks a contiguous run of tiles (XCD-remapped order: the
+// token tile stays, the feature tile advances) with ONE software pipeline flattened over (tile, k-step) — the first
+// k-step of tile t+1 is already in flight while tile t's last k-step is multiplied and its epilogue stores run.  The
+// SD Linear layers have SHORT reductions (K = 320: five k-steps), so a tile-per-workgroup kernel spends as long
+// filling its pipeline as multiplying; here the fill is paid once per workgroup.
+template <int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_p(const GbArgs g, const int tiles_per_wg) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
+  constexpr int ROWS = BMt + BNt;
+  constexpr int STAGE = ROWS * 128;
+  constexpr int IPW = ROWS / 8 / NW;
+  static_assert(ROWS % (8 * NW) == 0, "tile");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wm = wave % WGM, wn = wave / WGM;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int nk = g.K >> 6;
+
+  // workgroup b of XCD x = b & 7 takes the (b >> 3)-th run of that XCD's contiguous tile range
+  const int xcd = blockIdx.x & 7, q = ntile >> 3, r = ntile & 7;
+  const int xcd_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int xcd_count = xcd < r ? q + 1 : q;
+  const int run0 = (blockIdx.x >> 3) * tiles_per_wg;
+  const int my_tiles = min(tiles_per_wg, xcd_count - run0);
+  if (my_tiles <= 0) return;
+  const int tile0 = xcd_first + run0;
+
+  uint32_t src_off[IPW];
+  bool src_w[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) src_w[i] = (8 * (wave * IPW + i) + (lane >> 3)) >= BMt;
+  auto aim = [&](int tile) {  // per-lane DMA sources of a tile (k-step 0)
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int m0 = tm * BMt, n0 = tn * BNt;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int rr = 8 * (wave * IPW + i) + (lane >> 3);
+      const int c = (lane & 7) ^ ((rr >> 1) & 7);
+      if (rr < BMt) {
+        int m = m0 + rr;
+        if (m > g.M - 1) m = g.M - 1;
+        src_off[i] = (uint32_t)m * (uint32_t)g.K + c * 8;
+      } else {
+        src_off[i] = (uint32_t)(n0 + rr - BMt) * (uint32_t)g.K + c * 8;
+      }
+    }
+  };
+  auto issue = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const uint16_t *p = (src_w[i] ? g.w : g.x) + src_off[i] + ks * 64;
+      lds_ptr_t d = (lds_ptr_t)(lds + buf * STAGE + (wave * IPW + i) * 1024);
+      __builtin_amdgcn_global_load_lds(p, d, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+  const int sw = (lo >> 1) & 7;
+  const int x_row = (wm * 64 + lo) * 128;
+  const int w_row = (BMt + wn * 64 + lo) * 128;
+  int ch[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) ch[kk] = ((2 * kk + hi) ^ sw) * 16;
+
+  aim(tile0);
+  issue(0, 0);
+  int ks = 0, t = 0, buf = 0;
+  const int total = my_tiles * nk;
+  for (int f = 0; f < total; ++f) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    // next stage of the flattened (tile, k-step) sequence
+    int nks = ks + 1, nt = t;
+    if (nks == nk) { nks = 0; nt = t + 1; }
+    if (f + 1 < total) {
+      if (nks == 0) aim(tile0 + nt);
+      issue(nks, buf ^ 1);
+    }
+    const char *base = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const g_bf16x8 w0 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + ch[kk]);
+      const g_bf16x8 w1 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + 32 * 128 + ch[kk]);
+      const g_bf16x8 x0 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + ch[kk]);
+      const g_bf16x8 x1 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + 32 * 128 + ch[kk]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[1][1], 0, 0, 0);
+    }
+    if (ks == nk - 1) {  // tile done: store it (the next tile's first k-step is already in flight) and clear
+      const int tile = tile0 + t;
+      const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+      const int m0 = tm * BMt, n0 = tn * BNt;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int m = m0 + wm * 64 + b * 32 + lo;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int n = n0 + wn * 64 + a * 32 + 8 * qq + 4 * hi;
+            float o0 = acc[a][b][4 * qq], o1 = acc[a][b][4 * qq + 1], o2 = acc[a][b][4 * qq + 2], o3 = acc[a][b][4 * qq + 3];
+            acc[a][b][4 * qq] = 0.f; acc[a][b][4 * qq + 1] = 0.f; acc[a][b][4 * qq + 2] = 0.f; acc[a][b][4 * qq + 3] = 0.f;
+            if (m < g.M) {
+              if (g.bias) {
+                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n);
+                o0 += bv.x; o1 += bv.y; o2 += bv.z; o3 += bv.w;
+              }
+              const size_t e = (size_t)m * g.N + n;
+              if (g.addend) {
+                const uint2 av = *reinterpret_cast<const uint2 *>(g.addend + e);
+                o0 += gb_lo(av.x); o1 += gb_hi(av.x); o2 += gb_lo(av.y); o3 += gb_hi(av.y);
+              }
+              *reinterpret_cast<uint2 *>(g.y + e) = make_uint2(gb_pack2(o0, o1), gb_pack2(o2, o3));
+            }
+          }
+      }
+    }
+    ks = nks; t = nt; buf ^= 1;
+  }
+}
+
+// Ring form: NST stages of LDS, the DMA of stages f+1 .. f+NST-2 stays in flight ACROSS the barrier of step f (counted
+// `s_waitcnt vmcnt(N)`, raw `s_barrier` — `__syncthreads()` would drain the DMA queue, cdna_hip_programming.md §5
+// "Pipelining across barriers").  The measurements that asked for it (tools/gemmbench_bf16.py, round 4): with one stage
+// in flight a k-step took ~1.8 us against 0.21 us of MFMA work — the loop was bound by the latency of ONE global ->
+// LDS transfer per step, whatever the tile shape, single- or double-buffered, persistent or not.
+// Epilogue: the 64 x 64 result of a wave goes through that wave's own LDS region as [token][feature] fp32, so the
+// global stores are 16 bytes per lane and whole 128-byte lines per 8 lanes (the 8-byte strided stores of the first
+// version wrote a 168 MB output at 1.6 TB/s).
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt left at their maxima) for the counts the ring instantiations need, as
+// literal encodings.  (A hipcc / ROCm 7.2 trap met while writing this kernel, recorded here: when the SOURCE argument of
+// __builtin_amdgcn_global_load_lds is an rvalue expression such as `src[i] + ks * 64` instead of a named pointer, the
+// HOST pass silently fails to instantiate the kernel template and drops its launch stub — the library then fails to
+// load with an undefined `__device_stub__` symbol.  Hence the named `p` in `issue` below.)
+#define GB_WAIT_VM(N)                                                  \
+  do {                                                                 \
+    if constexpr ((N) == 0) __builtin_amdgcn_s_waitcnt(0x0f70);        \
+    else if constexpr ((N) == 6) __builtin_amdgcn_s_waitcnt(0x0f76);   \
+    else if constexpr ((N) == 8) __builtin_amdgcn_s_waitcnt(0x0f78);   \
+    else if constexpr ((N) == 10) __builtin_amdgcn_s_waitcnt(0x0f7a);  \
+    else if constexpr ((N) == 12) __builtin_amdgcn_s_waitcnt(0x0f7c);  \
+    else if constexpr ((N) == 16) __builtin_amdgcn_s_waitcnt(0x4f70);  \
+    else if constexpr ((N) == 20) __builtin_amdgcn_s_waitcnt(0x4f74);  \
+    else static_assert((N) < 0, "add the literal encoding of this vmcnt"); \
+  } while (0)
+
+template <int WGM, int WGN, int NST>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_r(const GbArgs g) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
+  constexpr int ROWS = BMt + BNt;
+  constexpr int STAGE = ROWS * 128;
+  constexpr int IPW = ROWS / 8 / NW;
+  constexpr int EROW = 64 * 4 + 16;  // epilogue row: 64 fp32 features + pad (16-byte aligned, spreads the banks)
+  static_assert(ROWS % (8 * NW) == 0 && NST >= 3 && NST <= 4, "tile");
+  static_assert(NW * 64 * EROW <= NST * STAGE, "epilogue staging fits the ring");
+  static_assert(IPW * (NST - 2) < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wm = wave % WGM, wn = wave / WGM;
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = ntile >> 3, r = ntile & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BMt, n0 = tn * BNt;
+
+  // Full per-lane source POINTERS, fixed before the loop: a per-lane choice between the two base pointers inside the
+  // loop makes hipcc fetch the base from the kernel-argument segment with an ordinary global load — and an ordinary load
+  // next to LDS-DMA makes it wait vmcnt(0), which drains the ring (cdna_hip_programming.md §5, trap (b)).
+  const uint16_t *src[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int rr = 8 * (wave * IPW + i) + (lane >> 3);
+    const int c = (lane & 7) ^ ((rr >> 1) & 7);
+    int m = m0 + rr;
+    if (m > g.M - 1) m = g.M - 1;
+    const uint16_t *px = g.x + (size_t)m * g.K + c * 8;
+    const uint16_t *pw = g.w + (size_t)(n0 + rr - BMt) * g.K + c * 8;
+    src[i] = (rr < BMt) ? px : pw;
+  }
+  auto issue = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      lds_ptr_t d = (lds_ptr_t)(lds + buf * STAGE + (wave * IPW + i) * 1024);
+      const uint16_t *p = src[i] + ks * 64;
+      __builtin_amdgcn_global_load_lds(p, d, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+  const int sw = (lo >> 1) & 7;
+  const int x_row = (wm * 64 + lo) * 128;
+  const int w_row = (BMt + wn * 64 + lo) * 128;
+  int ch[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) ch[kk] = ((2 * kk + hi) ^ sw) * 16;
+
+  auto compute = [&](int buf) {
+    const char *base = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const g_bf16x8 w0 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + ch[kk]);
+      const g_bf16x8 w1 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + 32 * 128 + ch[kk]);
+      const g_bf16x8 x0 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + ch[kk]);
+      const g_bf16x8 x1 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + 32 * 128 + ch[kk]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[1][1], 0, 0, 0);
+    }
+  };
+
+  const int nk = g.K >> 6;
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nk) issue(s0, s0);
+  int buf = 0, nbuf = NST - 1;
+  for (int f = 0; f < nk; ++f) {
+    // stage f must have landed; up to NST-2 later stages (fewer at the tail) stay in flight across the barrier
+    const int later = nk - 1 - f;
+    if (later >= NST - 2) GB_WAIT_VM(IPW * (NST - 2));
+    else if (NST == 4 && later == 1) GB_WAIT_VM(IPW);
+    else GB_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();  // every wave's share of stage f is in LDS; everyone has finished reading stage f-1
+    if (f + NST - 1 < nk) issue(f + NST - 1, nbuf);  // ... whose buffer is refilled now
+    compute(buf);
+    buf = (buf + 1 == NST) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
+  }
+
+  // ---- epilogue through LDS: wave-private region, [token 64][feature 64] fp32 rows of EROW bytes
+  __builtin_amdgcn_s_barrier();  // all waves are done with the stage buffers
+  char *er = lds + wave * (64 * EROW);
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // D[i = feature][j = token]: lane (token lo, half hi), registers 4q..4q+3: features 8q + 4hi + 0..3
+        float4 v4 = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+        *reinterpret_cast<float4 *>(er + (b * 32 + lo) * EROW + (a * 32 + 8 * q + 4 * hi) * 4) = v4;
+      }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (wave-private region: no barrier)
+  const int fr = (lane & 7) * 8;       // 8 features per lane, 8 lanes per token row
+  float bsv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsv[e] = 0.f;
+  if (g.bias) {
+    const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + n0 + wn * 64 + fr);
+    const float4 b1 = *reinterpret_cast<const float4 *>(g.bias + n0 + wn * 64 + fr + 4);
+    bsv[0] = b0.x; bsv[1] = b0.y; bsv[2] = b0.z; bsv[3] = b0.w; bsv[4] = b1.x; bsv[5] = b1.y; bsv[6] = b1.z; bsv[7] = b1.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int trow = i * 8 + (lane >> 3);
+    const int m = m0 + wm * 64 + trow;
+    const float4 u0 = *reinterpret_cast<const float4 *>(er + trow * EROW + fr * 4);
+    const float4 u1 = *reinterpret_cast<const float4 *>(er + trow * EROW + fr * 4 + 16);
+    if (m < g.M) {
+      float o[8] = {u0.x + bsv[0], u0.y + bsv[1], u0.z + bsv[2], u0.w + bsv[3],
+                    u1.x + bsv[4], u1.y + bsv[5], u1.z + bsv[6], u1.w + bsv[7]};
+      const size_t e = (size_t)m * g.N + n0 + wn * 64 + fr;
+      if (g.addend) {
+        const uint4 av = *reinterpret_cast<const uint4 *>(g.addend + e);
+        o[0] += gb_lo(av.x); o[1] += gb_hi(av.x); o[2] += gb_lo(av.y); o[3] += gb_hi(av.y);
+        o[4] += gb_lo(av.z); o[5] += gb_hi(av.z); o[6] += gb_lo(av.w); o[7] += gb_hi(av.w);
+      }
+      *reinterpret_cast<uint4 *>(g.y + e) = make_uint4(gb_pack2(o[0], o[1]), gb_pack2(o[2], o[3]), gb_pack2(o[4], o[5]),
+                                                       gb_pack2(o[6], o[7]));
+    }
+  }
+}
+
+template <int WGM, int WGN, int NST>
+int launch_gemm_bf16_r(const GbArgs &g0, hipStream_t st) {
+  GbArgs g = g0;
+  constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
+  g.tiles_m = (g.M + BMt - 1) / BMt;
+  g.tiles_n = g.N / BNt;
+  const size_t ldsb = (size_t)NST * (BMt + BNt) * 128;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt_r<WGM, WGN, NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_gemm_bf16_nt_r<WGM, WGN, NST>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
 // fp32 [N][K] -> bf16 [K][N] (the weight image the input-gradient GEMM reads); 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void k_pack_bf16_t(const float *__restrict__ w, uint16_t *__restrict__ wt, int N, int K) {
   __shared__ float tile[32][33];
@@ -707,6 +1026,31 @@ int launch_gemm_bf16(const GbArgs &g0, hipStream_t st) {
   return SALUN_OK;
 }
 
+template <int WGM, int WGN>
+int launch_gemm_bf16_p(const GbArgs &g0, hipStream_t st) {
+  GbArgs g = g0;
+  constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
+  g.tiles_m = (g.M + BMt - 1) / BMt;
+  g.tiles_n = g.N / BNt;
+  const size_t ldsb = (size_t)2 * (BMt + BNt) * 128;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt_p<WGM, WGN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    configured = true;
+  }
+  const int ntile = g.tiles_m * g.tiles_n;
+  // 2 workgroups per CU (LDS: 2 x 64-80 KB); each walks a run of tiles inside its XCD's contiguous range
+  const int per_xcd = (ntile + 7) / 8;
+  int runs = 64;                                   // workgroups per XCD
+  if (runs > per_xcd) runs = per_xcd;
+  const int tiles_per_wg = (per_xcd + runs - 1) / runs;
+  runs = (per_xcd + tiles_per_wg - 1) / tiles_per_wg;
+  hipLaunchKernelGGL((k_gemm_bf16_nt_p<WGM, WGN>), dim3(runs * 8), dim3(64 * WGM * WGN), ldsb, st, g, tiles_per_wg);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
 }  // namespace
 
 SALUN_EXPORT int salun_gemm_bf16_supported(int64_t M, int N, int K) {
@@ -715,7 +1059,8 @@ SALUN_EXPORT int salun_gemm_bf16_supported(int64_t M, int N, int K) {
 }
 
 // variant: 0 = choose; 1 = 128 tokens x 128 features double-buffered, 2 = same single-buffered, 3 = 256 tokens x 64
-// features double-buffered, 4 = same single-buffered (A/B measurements: tools/gemmbench_bf16.py)
+// features double-buffered, 4 = same single-buffered, 5 / 6 = the persistent forms of 1 / 3 (A/B measurements:
+// tools/gemmbench_bf16.py)
 SALUN_EXPORT int salun_gemm_bf16_nt(const void *x, const void *w, const float *bias, const void *addend, void *y, int64_t M,
                                     int N, int K, int variant, salun_stream_t stream) {
   if (!salun_gemm_bf16_supported(M, N, K) || !x || !w || !y) return SALUN_EINVAL;
@@ -727,13 +1072,24 @@ SALUN_EXPORT int salun_gemm_bf16_nt(const void *x, const void *w, const float *b
   g.addend = static_cast<const uint16_t *>(addend); g.y = static_cast<uint16_t *>(y);
   g.M = (int)M; g.N = N; g.K = K; g.tiles_m = g.tiles_n = 0;
   hipStream_t st = salun_hip_stream(stream);
-  if (variant == 0) variant = (N % 128 == 0) ? 1 : 3;
+  if (variant == 0) {
+    // measured on the SD shapes (profiles/r04_gemmbench_bf16.txt): the 8-wave 256 x 128 ring wins wherever it has >= ~128
+    // tiles; the 4-wave 128 x 128 ring on smaller problems; feature counts that are multiples of 64 only: 256 x 64
+    if (N % 128 != 0) variant = 3;
+    else variant = (((M + 255) / 256) * (int64_t)(N / 128) >= 128) ? 8 : 10;
+  }
   if ((variant == 1 || variant == 2) && N % 128 != 0) return SALUN_EINVAL;
   switch (variant) {
     case 1: return launch_gemm_bf16<2, 2, true>(g, st);
     case 2: return launch_gemm_bf16<2, 2, false>(g, st);
     case 3: return launch_gemm_bf16<4, 1, true>(g, st);
     case 4: return launch_gemm_bf16<4, 1, false>(g, st);
+    case 5: return (N % 128 == 0) ? launch_gemm_bf16_p<2, 2>(g, st) : SALUN_EINVAL;
+    case 6: return launch_gemm_bf16_p<4, 1>(g, st);
+    case 7: return (N % 128 == 0) ? launch_gemm_bf16_r<2, 2, 4>(g, st) : SALUN_EINVAL;   // 128 x 128, 4 stages (128 KB)
+    case 8: return (N % 128 == 0) ? launch_gemm_bf16_r<4, 2, 3>(g, st) : SALUN_EINVAL;   // 256 x 128, 8 waves, 3 stages (144 KB)
+    case 9: return launch_gemm_bf16_r<4, 1, 3>(g, st);                                   // 256 x 64, 3 stages (120 KB)
+    case 10: return (N % 128 == 0) ? launch_gemm_bf16_r<2, 2, 3>(g, st) : SALUN_EINVAL;  // 128 x 128, 3 stages (96 KB)
     default: return SALUN_EINVAL;
   }
 }

@@ -143,6 +143,7 @@ class _Linear(torch.autograd.Function):
             x2 = x2.contiguous()
         y = mm_nt(x2, weight, bias=bias)
         ctx.save_for_backward(x2, weight, bias)
+        ctx.params = (weight, bias)  # the Parameter objects (gradient destinations): saved_tensors may be detached aliases
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], weight.shape[0])
 
@@ -162,14 +163,14 @@ class _Linear(torch.autograd.Function):
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             # dW[n, k] = sum_m dY[m, n] x[m, k], added straight into the flat gradient when it can be
-            sink = gradsink.sink(weight)
+            sink = gradsink.sink(ctx.params[0])
             dst = sink if sink is not None else torch.empty_like(weight)
             launch([Job(dst.data_ptr(), N, K, dst.stride(0),
                         [Seg(dy2.data_ptr(), 1, dy2.stride(0), x2.data_ptr(), 1, x2.stride(0), x2.shape[0])],
                         accumulate=sink is not None)], dy.device)
             dw = None if sink is not None else dst
         if bias is not None and ctx.needs_input_grad[2]:
-            sink = gradsink.sink(bias)
+            sink = gradsink.sink(ctx.params[1])
             db = colsum(dy2, out=sink, accumulate=sink is not None)
             if sink is not None:
                 db = None
@@ -217,6 +218,7 @@ class _GroupedLinear(torch.autograd.Function):
                     for o, w, b in zip(outs[g0:g0 + 32], ws[g0:g0 + 32], bs[g0:g0 + 32])]
             launch(jobs, x.device)
         ctx.save_for_backward(x2, *ws)
+        ctx.weights = ws  # Parameter objects (gradient destinations)
         ctx.biases = bs
         ctx.G = G
         ctx.set_materialize_grads(False)  # a projection whose block saw no gradient arrives as None, not as zeros
@@ -243,7 +245,7 @@ class _GroupedLinear(torch.autograd.Function):
         for g, dy in live:
             if not ctx.needs_input_grad[1 + g]:
                 continue
-            sink = gradsink.sink(ws[g])
+            sink = gradsink.sink(ctx.weights[g])
             dst = sink if sink is not None else torch.empty_like(ws[g])
             keep.append(dst)
             jobs.append(Job(dst.data_ptr(), ws[g].shape[0], K, dst.stride(0),

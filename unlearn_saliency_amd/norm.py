@@ -23,6 +23,7 @@ class _FusedBN(torch.autograd.Function):
             raise RuntimeError("fused BN: unsupported shape (H*W must be a multiple of 4)")
         y, mean, invstd = out
         ctx.save_for_backward(x, y if relu else None, weight, bias, mean, invstd)
+        ctx.params = (weight, bias)  # Parameter objects for gradsink (saved_tensors are detached aliases under checkpointing)
         ctx.cfg = (bool(training), bool(relu), residual is not None)
         ctx.mark_non_differentiable(mean, invstd)
         return y
@@ -31,7 +32,7 @@ class _FusedBN(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, weight, bias, mean, invstd = ctx.saved_tensors
         training, relu, has_res = ctx.cfg
-        gw, gb = gradsink.sink(weight), gradsink.sink(bias)
+        gw, gb = gradsink.sink(ctx.params[0]), gradsink.sink(ctx.params[1])
         if gw is None or gb is None:
             gw = gb = None
         dx, dres, dgamma, dbeta = ops.bn_backward(dy.contiguous(), y, x, weight, mean, invstd, training, relu,
@@ -69,6 +70,7 @@ class _FusedGN(torch.autograd.Function):
             raise RuntimeError("fused GroupNorm: unsupported shape")
         z, mean, rstd = out
         ctx.save_for_backward(x, weight, bias, mean, rstd)  # y and sigmoid(y) are recomputed in backward
+        ctx.params = (weight, bias)
         ctx.cfg = (int(groups), bool(silu))
         return z
 
@@ -76,7 +78,7 @@ class _FusedGN(torch.autograd.Function):
     def backward(ctx, dz):
         x, weight, bias, mean, rstd = ctx.saved_tensors
         groups, silu = ctx.cfg
-        gw, gb = gradsink.sink(weight), gradsink.sink(bias)
+        gw, gb = gradsink.sink(ctx.params[0]), gradsink.sink(ctx.params[1])
         if gw is None or gb is None:
             gw = gb = None
         dx, dgamma, dbeta = ops.gn_backward(dz.contiguous(), x, weight, bias, mean, rstd, groups, silu, gw, gb)
@@ -94,6 +96,7 @@ class _FusedGN16(torch.autograd.Function):
         xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         y, mr, ab = ops.gn_bf16_forward(xn, weight, bias, groups, eps, silu)
         ctx.save_for_backward(xn, weight, bias, mr, ab)
+        ctx.params = (weight, bias)
         ctx.cfg = (int(groups), bool(silu))
         return y.permute(0, 3, 1, 2)
 
@@ -102,7 +105,7 @@ class _FusedGN16(torch.autograd.Function):
         xn, weight, bias, mr, ab = ctx.saved_tensors
         groups, silu = ctx.cfg
         dyn = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
-        gw, gb = gradsink.sink(weight), gradsink.sink(bias)
+        gw, gb = gradsink.sink(ctx.params[0]), gradsink.sink(ctx.params[1])
         sunk = gw is not None and gb is not None
         if not sunk:
             gw, gb = torch.empty_like(weight), torch.empty_like(bias)

@@ -633,6 +633,7 @@ class _LayerNorm16(torch.autograd.Function):
                                                c_void_p(stats.data_ptr()), c_int64(rows), C, c_double(eps), _stream()),
               "salun_ln_bf16_forward")
         ctx.save_for_backward(xc, weight, bias, stats)
+        ctx.params = (weight, bias)  # Parameter objects for gradsink (saved_tensors are detached aliases under checkpointing)
         return y
 
     @staticmethod
@@ -644,7 +645,7 @@ class _LayerNorm16(torch.autograd.Function):
         dyc = dy.to(torch.bfloat16).contiguous()
         L = _lib.lib()
         ws = workspace(L.salun_ln_bf16_workspace_bytes(c_int64(rows), C), xc.device)
-        gw, gb = gradsink.sink(weight), gradsink.sink(bias)
+        gw, gb = gradsink.sink(ctx.params[0]), gradsink.sink(ctx.params[1])
         sunk = gw is not None and gb is not None
         if not sunk:
             gw, gb = torch.empty_like(weight), torch.empty_like(bias)

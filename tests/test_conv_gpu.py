@@ -53,12 +53,12 @@ def test_conv_kernels_match_torch_cpu(N, C, H, K, R, stride, pad):
     xd, wd, bd, dyd = x.cuda(), w.cuda(), b.cuda(), dy.cuda()
     y = ops.conv2d_forward(xd, wd, bd, stride, pad, P, P)
     assert y is not None, "shape unexpectedly outside the tiling domain"
-    tol = lambda ref: 2e-5 * float(ref.abs().max())
-    assert torch.allclose(y.cpu(), y_ref, rtol=1e-5, atol=tol(y_ref))
+    tol = lambda ref: 6e-6 * float(ref.abs().max())  # rtol / atol: 3x the worst use measured (tools/measure_tolerances.py)
+    assert torch.allclose(y.cpu(), y_ref, rtol=3e-6, atol=tol(y_ref))
     dx = ops.conv2d_backward_data(dyd, wd, x.shape, stride, pad)
-    assert dx is not None and torch.allclose(dx.cpu(), dx_ref, rtol=1e-5, atol=tol(dx_ref))
+    assert dx is not None and torch.allclose(dx.cpu(), dx_ref, rtol=3e-6, atol=tol(dx_ref))
     dw = ops.conv2d_backward_weight(xd, dyd, w.shape, stride, pad)
-    assert dw is not None and torch.allclose(dw.cpu(), dw_ref, rtol=1e-5, atol=tol(dw_ref))
+    assert dw is not None and torch.allclose(dw.cpu(), dw_ref, rtol=3e-6, atol=tol(dw_ref))
     # deterministic run to run
     assert torch.equal(dw, ops.conv2d_backward_weight(xd, dyd, w.shape, stride, pad))
     assert torch.equal(y, ops.conv2d_forward(xd, wd, bd, stride, pad, P, P))
@@ -76,7 +76,7 @@ def test_asymmetric_padding_downsample():
     y2 = F.conv2d(F.pad(x2, (0, 1, 0, 1)), w2, b2, stride=2, padding=0)
     y2.square().sum().backward()
     for a, r in ((y, y2), (x.grad, x2.grad), (w.grad, w2.grad), (b.grad, b2.grad)):
-        assert torch.allclose(a, r, rtol=1e-4, atol=3e-5 * float(r.abs().max()))
+        assert torch.allclose(a, r, rtol=5e-6, atol=1.5e-6 * float(r.abs().max()))
 
 
 def test_unsupported_shape_falls_back():
@@ -140,7 +140,7 @@ def test_channel_sum_is_the_bias_gradient(N, K, H):
     view = d[:, :, :, :].permute(0, 1, 2, 3)[:, :, 1:, :]  # odd offset: 16-byte alignment lost -> scalar path
     if H > 1:
         v = view.contiguous()
-        assert torch.allclose(ops.channel_sum(v).cpu().double(), v.cpu().double().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-4)
+        assert torch.allclose(ops.channel_sum(v).cpu().double(), v.cpu().double().sum(dim=(0, 2, 3)), rtol=6e-6, atol=6e-5)
 
 
 def test_conv_bias_gradient_lands_in_the_flat_arena_without_autograd_adds():
@@ -161,4 +161,4 @@ def test_conv_bias_gradient_lands_in_the_flat_arena_without_autograd_adds():
         lib(x).square().mean().backward()
     assert own[0].bias.grad.data_ptr() == arena.grads[arena.offsets[1]:].data_ptr()
     for a, b in zip(own.parameters(), lib.parameters()):
-        assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6 * float(b.grad.abs().max())), a.shape
+        assert torch.allclose(a.grad, b.grad, rtol=6.6e-5, atol=6.6e-7 * float(b.grad.abs().max())), a.shape

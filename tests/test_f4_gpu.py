@@ -49,7 +49,7 @@ def test_samplers_on_device_match_reference(golden_dir, name):
 def test_sampling_through_the_own_unet_kernels():
     """`Diffusion.sample_image` (reference runners/diffusion.py:828-875) with the CFG-DDPM U-Net on the MFMA
     convolution / fused GroupNorm kernels against the same sampler on the library ops: 6 DDIM steps, two classes.
-    Tolerance 1e-4 of the sample's scale (six U-Net evaluations in fp32; measured ~1e-6)."""
+    Tolerance 1.5e-5 of the sample's scale = 3 x the 4.85e-6 measured on the MI355X (six U-Net evaluations in fp32)."""
     import copy
     from types import SimpleNamespace
     from unlearn_saliency_amd import conv as sconv
@@ -74,7 +74,7 @@ def test_sampling_through_the_own_unet_kernels():
     assert n_lib == 0, sconv.LIBRARY_CONV_CALLS
     err = float((a - b).abs().max() / b.abs().max())
     print(f"6-step DDIM sample, own kernels vs library ops: {err:.2e} of scale")
-    assert torch.isfinite(a).all() and err <= 1e-4, err
+    assert torch.isfinite(a).all() and err <= 1.5e-5, err
 
 
 @pytest.mark.parametrize("flat", [False, True])

@@ -39,7 +39,7 @@ def _deterministic():
     yield
 
 
-def _check_state(model, g, rtol=1e-4, atol=1e-6):
+def _check_state(model, g, rtol=1e-5, atol=2e-7):  # 3x the worst use measured on the MI355X (tools/measure_tolerances.py)
     for k, v in model.state_dict().items():
         assert np.allclose(v.cpu().numpy(), g["sd_" + k], rtol=rtol, atol=atol), k
 
@@ -168,7 +168,7 @@ def test_rl_proximal_plugin_matches_reference(golden_dir):
     unlearn.get_unlearn_method("RL_proximal")(loaders, model, nn.CrossEntropyLoss(),
                                               _args(unlearn="RL_proximal", mask_ratio=float(g["mask_ratio"])),
                                               {"ignored": None})
-    _check_state(model, g, rtol=1e-4, atol=2e-6)
+    _check_state(model, g, rtol=1e-5, atol=2e-7)
     with pytest.raises(AttributeError):
         unlearn.get_unlearn_method("RL_proximal")(loaders, model, nn.CrossEntropyLoss(), _args(), None)
 
@@ -194,7 +194,7 @@ def test_ga_ft_plugins_match_reference(golden_dir, name, tag):
     key, batches = ("forget", tiny_batches(2, 16, 700)) if name.startswith("GA") else ("retain", tiny_batches(3, 16, 800))
     args = _args(unlearn=name, alpha=float(g["alpha"]), no_l1_epochs=int(g["no_l1_epochs"]) if "no_l1_epochs" in g else 0)
     unlearn.get_unlearn_method(name)({key: _loader(batches)}, model, nn.CrossEntropyLoss(), args, mask)
-    _check_state(model, g, rtol=1e-4, atol=2e-6)
+    _check_state(model, g, rtol=1e-5, atol=2e-7)
     if mask is not None:
         names = [n for n, _ in model.named_parameters()]
         sd = model.state_dict()

@@ -32,20 +32,20 @@ def test_fused_bn_matches_torch(shape, training, relu, res):
     z2 = y2
     if relu:
         y2 = F.relu(y2)
-    assert torch.allclose(y, y2, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(y, y2, rtol=3e-5, atol=3e-6)  # every tolerance here: 3x the worst use measured on the MI355X
     # pre-activations within rounding of 0 may sit on different sides of the ReLU in the two computations:
     # give those (a handful out of millions) no upstream gradient so the comparison is well defined
     dy = torch.randn_like(y) * (z2.detach().abs() > 1e-5)
     y.backward(dy); y2.backward(dy)
-    tol = lambda t: 2e-5 * float(t.abs().max()) + 1e-6
-    assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=tol(x2.grad))
-    assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=1e-4, atol=tol(ref.weight.grad))
-    assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=1e-4, atol=tol(ref.bias.grad))
+    tol = lambda t: 1e-6 * float(t.abs().max()) + 5e-8
+    assert torch.allclose(x.grad, x2.grad, rtol=5e-6, atol=tol(x2.grad))
+    assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=5e-6, atol=tol(ref.weight.grad))
+    assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=5e-6, atol=tol(ref.bias.grad))
     if res:
         assert torch.allclose(r.grad, r2.grad, rtol=1e-5, atol=1e-6)
     if training:
         assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
-        assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-6)
+        assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-6, atol=1e-8)
         assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
 
 
@@ -81,7 +81,7 @@ def test_resnet18_fused_bn_matches_unfused(train, blocks):
         worst_b = max(worst_b, float((q.grad.double() - r.grad).abs().max()) / den)
     assert worst_b < 3 * worst_a + 1e-5, (worst_a, worst_b)
     for (k, u), v in zip(d.named_buffers(), b.buffers()):
-        assert torch.allclose(u.float(), v.float(), rtol=1e-4, atol=1e-5), k
+        assert torch.allclose(u.float(), v.float(), rtol=1e-6, atol=1e-7), k
     assert list(a.state_dict().keys()) == list(b.state_dict().keys())
 
 
@@ -157,13 +157,13 @@ def test_fused_group_norm_matches_torch(shape, groups, silu):
     x2 = x.detach().clone().requires_grad_(True)
     y2 = ref(x2)
     z2 = y2 * torch.sigmoid(y2) if silu else y2
-    assert torch.allclose(z, z2, rtol=1e-4, atol=2e-5)
+    assert torch.allclose(z, z2, rtol=1e-5, atol=2e-6)
     dz = torch.randn_like(z)
     z.backward(dz); z2.backward(dz)
-    tol = lambda t: 2e-5 * float(t.abs().max()) + 1e-6
-    assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=tol(x2.grad))
-    assert torch.allclose(gn.weight.grad, ref.weight.grad, rtol=1e-4, atol=tol(ref.weight.grad))
-    assert torch.allclose(gn.bias.grad, ref.bias.grad, rtol=1e-4, atol=tol(ref.bias.grad))
+    tol = lambda t: 5e-7 * float(t.abs().max()) + 2.5e-8
+    assert torch.allclose(x.grad, x2.grad, rtol=2.5e-6, atol=tol(x2.grad))
+    assert torch.allclose(gn.weight.grad, ref.weight.grad, rtol=2.5e-6, atol=tol(ref.weight.grad))
+    assert torch.allclose(gn.bias.grad, ref.bias.grad, rtol=2.5e-6, atol=tol(ref.bias.grad))
     # second backward accumulates into .grad in the kernel (gradsink) — equals doubling
     g1 = gn.weight.grad.clone()
     fused_gn_act(x.detach().requires_grad_(True), gn, silu=silu).backward(dz)

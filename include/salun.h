@@ -537,6 +537,16 @@ int salun_gemm_bf16_supported(int64_t M, int N, int K);
 int salun_gemm_bf16_nt(const void *x /*dev bf16*/, const void *w /*dev bf16*/, const float *bias /*dev or NULL*/,
                        const void *addend /*dev bf16 or NULL*/, void *y /*dev bf16*/, int64_t M, int N, int K,
                        int variant, salun_stream_t stream);
+/* Weight gradient of the same layers (and of 1x1 stride-1 convolutions: salun_conv2d_bf16_backward_weight routes them
+ * here):  dw[Na, Nb] fp32 (+= when accumulate) = dy[M, Na]^T . x[M, Nb]  (reference: autograd of F.linear / F.conv2d under
+ * the layers above).  The reduction index M is the slow axis of both operands: tiles go global -> LDS directly and the
+ * MFMA operands are gathered with transposing LDS reads.  Split over M into partials in `ws`
+ * (salun_gemm_bf16_tn_workspace_bytes) folded in index order — deterministic.  Na, Nb multiples of 32, M < 2^24.
+ * variant: 0 = choose, 1..3 = pin a tile (A/B measurements). */
+int salun_gemm_bf16_tn_supported(int64_t M, int Na, int Nb);
+size_t salun_gemm_bf16_tn_workspace_bytes(int64_t M, int Na, int Nb, int variant);
+int salun_gemm_bf16_tn(const void *dy /*dev bf16*/, const void *x /*dev bf16*/, float *dw /*dev*/, int64_t M, int Na, int Nb,
+                       int accumulate, int variant, void *ws /*dev or NULL*/, size_t ws_bytes, salun_stream_t stream);
 /* fp32 master weights w[N][K] -> the bf16 image the GEMM reads: [N][K] (transposed = 0) or [K][N] (transposed = 1).
  * Once per optimizer step per layer. */
 int salun_pack_bf16(const float *w /*dev*/, void *wp /*dev bf16*/, int N, int K, int transposed, salun_stream_t stream);

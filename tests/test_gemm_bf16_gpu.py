@@ -119,3 +119,42 @@ def test_transformer_block_with_residual_epilogues_matches_the_plain_block():
     assert rel(y1, y0) <= 3e-2 and rel(dx1, dx0) <= 3e-2
     for n in g0:
         assert rel(g1[n], g0[n]) <= 5e-2, n
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("M,Na,Nb", [(64, 32, 32), (616, 320, 768), (4096, 1280, 320), (1000, 96, 160), (2048, 1280, 1280),
+                                     (33, 64, 64), (32768, 320, 320)])
+def test_gemm_bf16_tn_weight_gradient_matches_fp32_matmul_of_the_rounded_operands(variant, M, Na, Nb):
+    """dW = dY^T . X (the reduction over tokens is the slow axis of both operands: transposing LDS reads), ragged token
+    counts (tokens past M read zeros), feature counts that end inside a 128-wide tile, split reductions, accumulation."""
+    from unlearn_saliency_amd import ops
+    dy, x = dev((M, Na), 11).bfloat16(), dev((M, Nb), 12).bfloat16()
+    want = dy.double().t() @ x.double()
+    got = ops.gemm_bf16_tn(dy, x, variant=variant)
+    assert got.dtype == torch.float32 and got.shape == (Na, Nb)
+    e = rel(got, want)
+    assert e <= 2e-6 * max(1.0, (M / 4096) ** 0.5), (variant, M, Na, Nb, e)   # fp32 accumulation of exact bf16 products
+    assert torch.equal(ops.gemm_bf16_tn(dy, x, variant=variant), got)  # fixed split order, no atomics
+    base = dev((Na, Nb), 13)
+    acc = base.clone()
+    ops.gemm_bf16_tn(dy, x, out=acc, accumulate=True, variant=variant)
+    assert rel(acc, base.double() + want) <= 3e-6 * max(1.0, (M / 4096) ** 0.5)
+    # transpose-detecting: the operands are not symmetric, so dW^T would fail the first check; also X and dY swapped
+    if Na == Nb:
+        assert rel(got.t(), want) > 1e-2
+
+
+def test_conv_1x1_and_linear_weight_gradients_take_the_tn_kernel_and_agree_with_the_tap_kernel():
+    """salun_conv2d_bf16_backward_weight routes 1x1 / stride 1 / no padding to the TN GEMM; the bias gradient rides along."""
+    from unlearn_saliency_amd import ops
+    N, H, W, C, K = 2, 16, 16, 320, 640
+    x, dy = dev((N, H, W, C), 21).bfloat16(), dev((N, H, W, K), 22).bfloat16()
+    db = torch.zeros(K, device="cuda")
+    dw = ops.conv2d_bf16_backward_weight(x, dy, (K, C, 1, 1), 1, 0, bias_out=db)
+    want = dy.view(-1, K).double().t() @ x.view(-1, C).double()
+    assert rel(dw.view(K, C), want) <= 2e-6
+    assert rel(db, dy.view(-1, K).double().sum(0)) <= 2e-6
+    # accumulate into an existing gradient (the gradient sinks of the flat arena)
+    dw2 = dw.clone()
+    ops.conv2d_bf16_backward_weight(x, dy, (K, C, 1, 1), 1, 0, out=dw2, accumulate=True)
+    assert rel(dw2, 2 * dw.double()) <= 2e-6

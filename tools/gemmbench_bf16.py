@@ -58,6 +58,37 @@ def main():
         print(row, flush=True)
         tot["lib"] += t_lib; tot["best"] += best; tot["k11"] += t11
     print(f"sum over shapes: library {tot['lib']:.0f} us, best K16 variant {tot['best']:.0f} us, K11 {tot['k11']:.0f} us")
+    tn(a, shapes)
+
+
+def tn(a, shapes):
+    """Weight gradients dW[N, K] = dY[M, N]^T . X[M, K]: K16's TN variants vs the library (bf16 result) vs K11's tap kernel."""
+    from unlearn_saliency_amd import ops
+    os.environ["SALUN_WGRAD_TN"] = "0"   # read once by the library: the K11 column below is the tap kernel
+    print(f"\nweight gradient  {'M':>6} {'N':>6} {'K':>5} | {'lib us':>8} {'TF':>6} | "
+          + " ".join(f"{'tn%d us' % v:>8} {'TF':>6}" for v in (1, 2, 3)) + f" | {'K11 us':>8} {'TF':>6}")
+    tot = {"lib": 0.0, "best": 0.0, "k11": 0.0}
+    for M, N, K in shapes:
+        x = torch.randn(M, K, device="cuda").bfloat16()
+        dy = torch.randn(M, N, device="cuda").bfloat16()
+        dw = torch.zeros(N, K, device="cuda")
+        fl = 2.0 * M * N * K
+        t_lib = timeit(lambda: torch.mm(dy.t(), x), a.reps)
+        row = f"                 {M:>6} {N:>6} {K:>5} | {t_lib:8.1f} {fl / t_lib / 1e6:6.0f} | "
+        best = 1e9
+        for v in (1, 2, 3):
+            t = timeit(lambda: ops.gemm_bf16_tn(dy, x, out=dw, accumulate=True, variant=v), a.reps)
+            best = min(best, t)
+            row += f"{t:8.1f} {fl / t / 1e6:6.0f} "
+        if M % 8 == 0:
+            xn, dyn = x.view(1, M // 8, 8, K), dy.view(1, M // 8, 8, N)
+            t11 = timeit(lambda: ops.conv2d_bf16_backward_weight(xn, dyn, (N, K, 1, 1), 1, 0, out=dw.view(N, K, 1, 1), accumulate=True), a.reps)
+        else:
+            t11 = float("nan")
+        row += f"| {t11:8.1f} {fl / t11 / 1e6:6.0f}"
+        print(row, flush=True)
+        tot["lib"] += t_lib; tot["best"] += best; tot["k11"] += t11
+    print(f"sum over shapes: library {tot['lib']:.0f} us, best TN variant {tot['best']:.0f} us, K11 tap kernel {tot['k11']:.0f} us")
 
 
 if __name__ == "__main__":

@@ -129,6 +129,9 @@ SIGNATURES = {
     "salun_gemm_bf16_supported": (c_int, [c_int64, c_int, c_int]),
     "salun_gemm_bf16_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "salun_pack_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "salun_gemm_bf16_tn_supported": (c_int, [c_int64, c_int, c_int]),
+    "salun_gemm_bf16_tn_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "salun_gemm_bf16_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_uint64, c_void_p, c_void_p]),
     "salun_u64_add": (c_int, [c_void_p, c_uint64, c_void_p]),
     "salun_fill_uniform": (c_int, [c_void_p, c_int64, c_uint64, c_double, c_double, c_void_p]),

@@ -704,9 +704,26 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_data(const uint16_t *dy, const uint1
   return dispatch_igemm<true>(a, ws, ws_bytes, salun_hip_stream(stream));
 }
 
+// 1x1 stride-1 unpadded convolutions (and the Linear layers, which arrive as such) are plain dY^T . X products: K16's
+// TN kernel (salun_gemm.hip) takes them.  SALUN_WGRAD_TN=0 keeps them on the tap kernel below (A/B measurements).
+extern "C" int salun_gemm_bf16_tn_supported(int64_t M, int Na, int Nb);
+extern "C" size_t salun_gemm_bf16_tn_workspace_bytes(int64_t M, int Na, int Nb, int variant);
+extern "C" int salun_gemm_bf16_tn(const void *dy, const void *x, float *dw, int64_t M, int Na, int Nb, int accumulate, int variant,
+                                  void *ws, size_t ws_bytes, salun_stream_t stream);
+static bool tn_route(int64_t M, int C, int K, int R, int stride, int pad) {
+  static const int on = [] { const char *e = getenv("SALUN_WGRAD_TN"); return e ? atoi(e) : 1; }();
+  return on && R == 1 && stride == 1 && pad == 0 && salun_gemm_bf16_tn_supported(M, K, C);
+}
+
 SALUN_EXPORT size_t salun_conv2d_bf16_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad) {
   if (!supported(C, K, R, stride, pad) || N < 1) return 0;
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+  if (tn_route((int64_t)N * H * W, C, K, R, stride, pad)) {
+    // never 0 ("unsupported"): the column-sum partials of the bias gradient follow the GEMM's partials
+    size_t b = salun_gemm_bf16_tn_workspace_bytes((int64_t)N * H * W, K, C, 0);
+    b = (b + 255) & ~(size_t)255;
+    return b + (size_t)COLSUM_CHUNKS * K * sizeof(float);
+  }
   const int chunks = N * ((OH + 7) / 8) * ((OW + 7) / 8);
   const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
   return (size_t)wgrad_splits(tiles, chunks) * R * R * K * C * sizeof(float) + (size_t)COLSUM_CHUNKS * K * sizeof(float);
@@ -721,6 +738,25 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
   const size_t need = salun_conv2d_bf16_wgrad_workspace_bytes(N, H, W, C, K, R, stride, pad);
   if (ws_bytes < need) return SALUN_ENOSPC;
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+  if (tn_route((int64_t)N * H * W, C, K, R, stride, pad)) {
+    const int64_t M = (int64_t)N * H * W;
+    size_t gb = salun_gemm_bf16_tn_workspace_bytes(M, K, C, 0);
+    const int rc = salun_gemm_bf16_tn(dy, x, dw, M, K, C, accumulate, 0, ws, gb, stream);
+    if (rc != SALUN_OK) return rc;
+    if (db) {
+      gb = (gb + 255) & ~(size_t)255;
+      hipStream_t st = salun_hip_stream(stream);
+      int chunks = (int)((M + 63) / 64);
+      if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
+      const int64_t rpc = (M + chunks - 1) / chunks;
+      float *cpart = reinterpret_cast<float *>(static_cast<char *>(ws) + gb);
+      hipLaunchKernelGGL(k_colsum_partial, dim3((K / 8 + 31) / 32, chunks), dim3(256), 0, st, dy, cpart, M, K, rpc);
+      SALUN_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, cpart, db, K, chunks, accumulate);
+      SALUN_LAUNCH_CHECK();
+    }
+    return SALUN_OK;
+  }
   WgArgs a;
   a.x = x; a.dy = dy; a.part = static_cast<float *>(ws);
   a.N = N; a.H = H; a.W = W; a.C = C; a.OH = OH; a.OW = OW; a.K = K; a.pad = pad;

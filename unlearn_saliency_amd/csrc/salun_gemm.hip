@@ -811,6 +811,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_p(const GbArgs 
 #define GB_WAIT_VM(N)                                                  \
   do {                                                                 \
     if constexpr ((N) == 0) __builtin_amdgcn_s_waitcnt(0x0f70);        \
+    else if constexpr ((N) == 4) __builtin_amdgcn_s_waitcnt(0x0f74);   \
     else if constexpr ((N) == 6) __builtin_amdgcn_s_waitcnt(0x0f76);   \
     else if constexpr ((N) == 8) __builtin_amdgcn_s_waitcnt(0x0f78);   \
     else if constexpr ((N) == 10) __builtin_amdgcn_s_waitcnt(0x0f7a);  \
@@ -980,6 +981,254 @@ int launch_gemm_bf16_r(const GbArgs &g0, hipStream_t st) {
   return SALUN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ K16 TN (weight gradients)
+// dW[Na][Nb] (fp32) (+)= sum_m dY[m][Na] . X[m][Nb]: the reduction index is the SLOW axis of both operands, so the 16-byte
+// pieces the DMA drops into LDS hold 8 features of ONE token and an MFMA operand (8 tokens of one feature) is gathered by
+// the transposing LDS read `ds_read_b64_tr_b16` (two per operand; layout and lane mapping as in K11's backward-weight,
+// salun_conv_bf16.hip `tr_operand`).  Same ring as above (stages in flight across raw barriers); a stage = RST tokens of
+// the (TA + TB) features of the tile, stored as [32-feature block][token][64 bytes] — lane-linear for the DMA (a wave
+// instruction fills 16 tokens of one block), conflict-free for the transposing reads (a half-wave reads 4 whole 64-byte
+// token rows twice).  Tokens past M and feature blocks past Na / Nb read a 16-byte zero word instead.
+// The reduction is cut into `splits` ranges of whole stages (blockIdx.y); one range writes / adds into dW directly,
+// several write fp32 partials that k_tn_reduce folds in index order (deterministic, no atomics).
+typedef short g_s16x4 __attribute__((ext_vector_type(4)));
+typedef g_s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr_t;
+__device__ uint4 g_tn_zero = {0u, 0u, 0u, 0u};
+
+struct TnArgs {
+  const uint16_t *dy;  // [M][Na] bf16
+  const uint16_t *x;   // [M][Nb] bf16
+  float *out;          // dW [Na][Nb] (splits == 1) or partials [splits][Na][Nb]
+  int M, Na, Nb;
+  int tiles_a, tiles_b;
+  int stages, per_split;  // stages of RST tokens in total / per split
+  int accumulate;         // splits == 1 only: dW += instead of dW =
+};
+
+// One stage of MFMA work as ONE hand-scheduled block.  With the `__builtin_amdgcn_ds_read_tr16_b64` intrinsic hipcc's
+// wait-count pass cannot tell the transposing read from the LDS-DMA writes still in flight and puts `s_waitcnt vmcnt(0)` in
+// front of the first read of every stage, which drains the ring; inline assembly carries no memory operand, so the counted
+// waits + barrier of the loop stay the only synchronisation (they are sufficient: a stage is read only after its own wait
+// and barrier).  Fragments live in fixed registers v[160:191] (two sets: the reads of 16-token step k+1 are in flight
+// under the MFMAs of step k); `lgkmcnt` is counted in LDS reads — the block issues nothing else on that counter.
+// Set S: dY operands v[S:S+3], v[S+4:S+7] (feature blocks 0, 1), X operands v[S+8:S+11], v[S+12:S+15].
+#define TN_STR2(x) #x
+#define TN_STR(x) TN_STR2(x)
+#define TN_RD(S0, S1, S2, S3, S4, S5, S6, S7, OFF)                                          \
+  "ds_read_b64_tr_b16 v[" S0 "], %4 offset:" TN_STR(OFF) "\n\t"                              \
+  "ds_read_b64_tr_b16 v[" S1 "], %4 offset:" TN_STR(OFF) "+256\n\t"                          \
+  "ds_read_b64_tr_b16 v[" S4 "], %6 offset:" TN_STR(OFF) "\n\t"                              \
+  "ds_read_b64_tr_b16 v[" S5 "], %6 offset:" TN_STR(OFF) "+256\n\t"                          \
+  "ds_read_b64_tr_b16 v[" S2 "], %5 offset:" TN_STR(OFF) "\n\t"                              \
+  "ds_read_b64_tr_b16 v[" S3 "], %5 offset:" TN_STR(OFF) "+256\n\t"                          \
+  "ds_read_b64_tr_b16 v[" S6 "], %7 offset:" TN_STR(OFF) "\n\t"                              \
+  "ds_read_b64_tr_b16 v[" S7 "], %7 offset:" TN_STR(OFF) "+256\n\t"
+#define TN_RD_A(OFF) TN_RD("160:161", "162:163", "164:165", "166:167", "168:169", "170:171", "172:173", "174:175", OFF)
+#define TN_RD_B(OFF) TN_RD("176:177", "178:179", "180:181", "182:183", "184:185", "186:187", "188:189", "190:191", OFF)
+#define TN_MM(D0, D1, X0, X1)                                            \
+  "v_mfma_f32_32x32x16_bf16 %0, v[" D0 "], v[" X0 "], %0\n\t"             \
+  "v_mfma_f32_32x32x16_bf16 %1, v[" D0 "], v[" X1 "], %1\n\t"             \
+  "v_mfma_f32_32x32x16_bf16 %2, v[" D1 "], v[" X0 "], %2\n\t"             \
+  "v_mfma_f32_32x32x16_bf16 %3, v[" D1 "], v[" X1 "], %3\n\t"
+#define TN_MM_A TN_MM("160:163", "164:167", "168:171", "172:175")
+#define TN_MM_B TN_MM("176:179", "180:183", "184:187", "188:191")
+#define TN_CLOBBERS                                                                                                      \
+  "memory", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", \
+      "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", \
+      "v189", "v190", "v191"
+
+// a0, a1: LDS byte addresses of this lane's piece in the wave's two dY feature blocks; b0, b1: in its two X blocks
+template <int RST>
+__device__ __forceinline__ void tn_stage(f32x16 &c00, f32x16 &c01, f32x16 &c10, f32x16 &c11, uint32_t a0, uint32_t a1,
+                                         uint32_t b0, uint32_t b1) {
+  if constexpr (RST == 32) {
+    asm volatile(TN_RD_A(0) TN_RD_B(1024)
+                 "s_waitcnt lgkmcnt(8)\n\t" TN_MM_A
+                 "s_waitcnt lgkmcnt(0)\n\t" TN_MM_B
+                 : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
+                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+                 : TN_CLOBBERS);
+  } else {
+    asm volatile(TN_RD_A(0) TN_RD_B(1024)
+                 "s_waitcnt lgkmcnt(8)\n\t" TN_MM_A TN_RD_A(2048)
+                 "s_waitcnt lgkmcnt(8)\n\t" TN_MM_B TN_RD_B(3072)
+                 "s_waitcnt lgkmcnt(8)\n\t" TN_MM_A
+                 "s_waitcnt lgkmcnt(0)\n\t" TN_MM_B
+                 : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
+                 : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+                 : TN_CLOBBERS);
+  }
+}
+
+template <int WGA, int WGB, int RST, int NST>
+__global__ __launch_bounds__(64 * WGA * WGB) void k_gemm_bf16_tn(const TnArgs g) {
+  constexpr int NW = WGA * WGB;
+  constexpr int TA = 64 * WGA, TB = 64 * WGB;
+  constexpr int BLK = RST * 64;                 // bytes of one [RST tokens][32 features] block
+  constexpr int NBLK = (TA + TB) / 32;
+  constexpr int STAGE = NBLK * BLK;
+  constexpr int UPB = RST / 16;                 // 1 KB DMA units per block
+  constexpr int IPW = NBLK * UPB / NW;
+  static_assert((NBLK * UPB) % NW == 0 && NST >= 3 && NST <= 4 && (RST == 32 || RST == 64), "tile");
+  static_assert(IPW * (NST - 2) < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave % WGA, wb = wave / WGA;
+  const int ntile = g.tiles_a * g.tiles_b;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = ntile >> 3, r = ntile & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int ta = tile / g.tiles_b, tb = tile - ta * g.tiles_b;
+  const int a0 = ta * TA, b0 = tb * TB;
+  const int split = blockIdx.y;
+  const int sb = split * g.per_split;
+  const int se = min(g.stages, sb + g.per_split);
+  const int nk = se - sb;
+
+  // per-lane source pointers and strides, fixed before the loop (see the note on `src` in k_gemm_bf16_nt_r)
+  const uint16_t *zp = reinterpret_cast<const uint16_t *>(&g_tn_zero);
+  const uint16_t *src[IPW];
+  int adv[IPW];
+  const int tok0 = sb * RST + (lane >> 2);      // + 16 * (unit's token group)
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int u = wave * IPW + i;
+    const int blk = u / UPB, tg = u % UPB;
+    const bool isa = blk < TA / 32;
+    const int col = isa ? a0 + blk * 32 : b0 + (blk - TA / 32) * 32;
+    const int ld = isa ? g.Na : g.Nb;
+    const bool ok = col < ld;
+    const uint16_t *base = isa ? g.dy : g.x;
+    src[i] = ok ? base + (size_t)(tok0 + 16 * tg) * ld + col + (lane & 3) * 8 : zp;
+    adv[i] = ok ? RST * ld : 0;
+  }
+  int left[UPB];                                // tokens of this lane's row still inside M, per token group
+#pragma unroll
+  for (int t = 0; t < UPB; ++t) left[t] = g.M - (tok0 + 16 * t);
+
+  auto issue = [&](int s, int buf) {            // s: stage index relative to sb
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int u = wave * IPW + i;
+      lds_ptr_t d = (lds_ptr_t)(lds + buf * STAGE + u * 1024);
+      const uint16_t *q = src[i] + (size_t)s * adv[i];
+      const uint16_t *p = (left[u % UPB] > s * RST) ? q : zp;
+      __builtin_amdgcn_global_load_lds(p, d, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+  // transposing reads: 16-lane group gq, lane sl -> tokens 8*(gq>>1) + (sl>>2) (and +4), features 16*(gq&1) + 4*(sl&3)
+  const int gq = lane >> 4, sl = lane & 15;
+  const uint32_t frag = (uint32_t)((8 * (gq >> 1) + (sl >> 2)) * 64 + (16 * (gq & 1) + 4 * (sl & 3)) * 2);
+  const uint32_t a_off = (uint32_t)(wa * 2 * BLK) + frag;
+  const uint32_t b_off = (uint32_t)((TA / 32 + wb * 2) * BLK) + frag;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+  auto compute = [&](int buf) {
+    const uint32_t base = lds0 + (uint32_t)(buf * STAGE);
+    tn_stage<RST>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], base + a_off, base + a_off + BLK, base + b_off, base + b_off + BLK);
+  };
+
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nk) issue(s0, s0);
+  int buf = 0, nbuf = NST - 1;
+  for (int f = 0; f < nk; ++f) {
+    const int later = nk - 1 - f;
+    if (later >= NST - 2) GB_WAIT_VM(IPW * (NST - 2));
+    else if (NST == 4 && later == 1) GB_WAIT_VM(IPW);
+    else GB_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    if (f + NST - 1 < nk) issue(f + NST - 1, nbuf);
+    compute(buf);
+    buf = (buf + 1 == NST) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
+  }
+
+  // D[i = dY feature][j = X feature]: lane (j = lane & 31, half hi), register v: i = (v & 3) + 8 (v >> 2) + 4 hi.
+  // 32 lanes write 128 contiguous bytes of one dW row.
+  const int lo = lane & 31, hi = lane >> 5;
+  float *out = g.out + (size_t)split * g.Na * g.Nb;
+  const bool add = g.accumulate != 0;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int c = b0 + wb * 64 + b * 32 + lo;
+    if (c >= g.Nb) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int n = a0 + wa * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+        if (n < g.Na) {
+          float *dst = out + (size_t)n * g.Nb + c;
+          *dst = add ? *dst + acc[a][b][v] : acc[a][b][v];
+        }
+      }
+  }
+}
+
+// dw[i] (+)= sum_z part[z][i], z in index order; 4 elements per thread
+__global__ __launch_bounds__(256) void k_tn_reduce(const float *__restrict__ part, float *__restrict__ dw, int64_t n4, int64_t n,
+                                                   int splits, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 s = accumulate ? *reinterpret_cast<const float4 *>(dw + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+      const float4 v = *reinterpret_cast<const float4 *>(part + (size_t)z * n + 4 * i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(dw + 4 * i) = s;
+  }
+}
+
+struct TnPlan { int variant, ta, tb, rst, tiles_a, tiles_b, stages, splits, per_split; };
+
+// variant 1: 128 x 128, 64-token stages x 3 (96 KB, one workgroup per CU); 2: 128 x 128, 32-token stages x 4 (64 KB, two
+// per CU); 3: 256 x 128, 8 waves, 64-token stages x 3 (144 KB)
+TnPlan tn_plan(int64_t M, int Na, int Nb, int variant) {
+  TnPlan p;
+  if (variant == 0) variant = 2;
+  p.variant = variant;
+  p.ta = variant == 3 ? 256 : 128; p.tb = 128;
+  p.rst = variant == 2 ? 32 : 64;
+  p.tiles_a = (Na + p.ta - 1) / p.ta; p.tiles_b = (Nb + p.tb - 1) / p.tb;
+  p.stages = (int)((M + p.rst - 1) / p.rst);
+  const int tiles = p.tiles_a * p.tiles_b;
+  const int min_stages = 256 / p.rst;           // a split reduces over >= 256 tokens
+  int splits = (512 + tiles - 1) / tiles;
+  if (splits > p.stages / min_stages) splits = p.stages / min_stages;
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  p.per_split = (p.stages + splits - 1) / splits;
+  p.splits = (p.stages + p.per_split - 1) / p.per_split;
+  return p;
+}
+
+template <int WGA, int WGB, int RST, int NST>
+int launch_gemm_bf16_tn(const TnArgs &g, int splits, hipStream_t st) {
+  const size_t ldsb = (size_t)NST * (64 * WGA + 64 * WGB) / 32 * RST * 64;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_tn<WGA, WGB, RST, NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_gemm_bf16_tn<WGA, WGB, RST, NST>), dim3(g.tiles_a * g.tiles_b, splits), dim3(64 * WGA * WGB), ldsb, st, g);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
 // fp32 [N][K] -> bf16 [K][N] (the weight image the input-gradient GEMM reads); 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void k_pack_bf16_t(const float *__restrict__ w, uint16_t *__restrict__ wt, int N, int K) {
   __shared__ float tile[32][33];
@@ -1092,6 +1341,48 @@ SALUN_EXPORT int salun_gemm_bf16_nt(const void *x, const void *w, const float *b
     case 10: return (N % 128 == 0) ? launch_gemm_bf16_r<2, 2, 3>(g, st) : SALUN_EINVAL;  // 128 x 128, 3 stages (96 KB)
     default: return SALUN_EINVAL;
   }
+}
+
+// dW fp32 [Na][Nb] (+= when accumulate) = dY^T . X over M tokens; dY bf16 [M][Na], X bf16 [M][Nb].  Na, Nb multiples of
+// 32.  `ws` holds the split partials (salun_gemm_bf16_tn_workspace_bytes; may be null when that is 0).
+SALUN_EXPORT int salun_gemm_bf16_tn_supported(int64_t M, int Na, int Nb) {
+  return M >= 1 && M < (int64_t(1) << 24) && Na >= 32 && Nb >= 32 && Na % 32 == 0 && Nb % 32 == 0 &&
+         (int64_t)M * Na < (int64_t(1) << 31) && (int64_t)M * Nb < (int64_t(1) << 31);
+}
+
+SALUN_EXPORT size_t salun_gemm_bf16_tn_workspace_bytes(int64_t M, int Na, int Nb, int variant) {
+  if (!salun_gemm_bf16_tn_supported(M, Na, Nb)) return 0;
+  const TnPlan p = tn_plan(M, Na, Nb, variant);
+  return p.splits > 1 ? (size_t)p.splits * Na * Nb * sizeof(float) : 0;
+}
+
+SALUN_EXPORT int salun_gemm_bf16_tn(const void *dy, const void *x, float *dw, int64_t M, int Na, int Nb, int accumulate,
+                                    int variant, void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (!salun_gemm_bf16_tn_supported(M, Na, Nb) || !dy || !x || !dw || variant < 0 || variant > 3) return SALUN_EINVAL;
+  if (!salun_aligned16(dy) || !salun_aligned16(x) || !salun_aligned16(dw)) return SALUN_EINVAL;
+  const TnPlan p = tn_plan(M, Na, Nb, variant);
+  const size_t need = p.splits > 1 ? (size_t)p.splits * Na * Nb * sizeof(float) : 0;
+  if (need && (!ws || ws_bytes < need || !salun_aligned16(ws))) return SALUN_ENOSPC;
+  TnArgs g;
+  g.dy = static_cast<const uint16_t *>(dy); g.x = static_cast<const uint16_t *>(x);
+  g.out = p.splits > 1 ? static_cast<float *>(ws) : dw;
+  g.M = (int)M; g.Na = Na; g.Nb = Nb; g.tiles_a = p.tiles_a; g.tiles_b = p.tiles_b;
+  g.stages = p.stages; g.per_split = p.per_split; g.accumulate = (p.splits == 1 && accumulate) ? 1 : 0;
+  hipStream_t st = salun_hip_stream(stream);
+  int rc;
+  if (p.variant == 1) rc = launch_gemm_bf16_tn<2, 2, 64, 3>(g, p.splits, st);
+  else if (p.variant == 2) rc = launch_gemm_bf16_tn<2, 2, 32, 4>(g, p.splits, st);
+  else rc = launch_gemm_bf16_tn<4, 2, 64, 3>(g, p.splits, st);
+  if (rc != SALUN_OK) return rc;
+  if (p.splits > 1) {
+    const int64_t n = (int64_t)Na * Nb, n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(ws), dw, n4, n, p.splits,
+                       accumulate);
+    SALUN_LAUNCH_CHECK();
+  }
+  return SALUN_OK;
 }
 
 SALUN_EXPORT int salun_pack_bf16(const float *w, void *wp, int N, int K, int transposed, salun_stream_t stream) {

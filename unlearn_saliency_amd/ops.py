@@ -504,6 +504,29 @@ def gemm_bf16_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     return y
 
 
+def gemm_bf16_tn_supported(M: int, Na: int, Nb: int) -> bool:
+    return bool(_lib.lib().salun_gemm_bf16_tn_supported(c_int64(M), int(Na), int(Nb)))
+
+
+def gemm_bf16_tn(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False,
+                 variant: int = 0) -> torch.Tensor:
+    """dw[Na, Nb] fp32 (+= into `out` when accumulate) = dy[M, Na]^T . x[M, Nb]; dy, x contiguous bf16."""
+    M, Na = dy.shape
+    Nb = x.shape[1]
+    assert x.shape[0] == M
+    L = _lib.lib()
+    if not L.salun_gemm_bf16_tn_supported(c_int64(M), Na, Nb):
+        raise ValueError(f"gemm_bf16_tn: unsupported shape M={M} Na={Na} Nb={Nb}")
+    nbytes = L.salun_gemm_bf16_tn_workspace_bytes(c_int64(M), Na, Nb, int(variant))
+    ws = workspace(nbytes, x.device) if nbytes else None
+    dw = out if out is not None else torch.empty((Na, Nb), dtype=torch.float32, device=x.device)
+    check(L.salun_gemm_bf16_tn(_dev(dy, torch.bfloat16, "dy"), _dev(x, torch.bfloat16, "x"), _dev(dw, torch.float32, "dw"),
+                               c_int64(M), Na, Nb, int(bool(accumulate and out is not None)), int(variant),
+                               c_void_p(ws.data_ptr() if ws is not None else None), c_size_t(nbytes), _stream()),
+          "salun_gemm_bf16_tn")
+    return dw
+
+
 def pack_bf16(w: torch.Tensor, transposed: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 [N, K] master weights -> bf16 [N, K] (or [K, N] with `transposed`): the images gemm_bf16_nt reads."""
     N, K = w.shape

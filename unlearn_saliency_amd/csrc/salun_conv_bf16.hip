@@ -354,6 +354,8 @@ struct WgArgs {
   const uint16_t *x;   // [N][H][W][C] bf16
   const uint16_t *dy;  // [N][OH][OW][K] bf16
   float *part;         // [split][RS][K][C] fp32 partial sums
+  float *dw;           // direct: the OIHW gradient itself (one split: no partials, no reduce launch)
+  int direct, accumulate;
   int N, H, W, C, OH, OW, K, pad;
   int tiles_h, tiles_w;       // 8x8 output-pixel chunks per image
   int chunks, per_split;      // total chunks, chunks per split
@@ -463,6 +465,22 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
 
   // ---- partials: part[split][tap][k][c]; D row = k, col = c
   const int c = c0 + wc * 32 + (lane & 31);
+  if (g.direct) {
+    // one split: this workgroup holds the whole sum of its (k, c) tile — a lane owns all R*R taps of an element, i.e.
+    // R*R consecutive floats of the OIHW gradient, and the 32 lanes of a row 32*R*R consecutive floats
+    if (c < g.C) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k = k0 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        if (k < g.K) {
+          float *dst = g.dw + ((size_t)k * g.C + c) * RS;
+#pragma unroll
+          for (int t = 0; t < RS; ++t) dst[t] = g.accumulate ? dst[t] + acc[t][v] : acc[t][v];
+        }
+      }
+    }
+    return;
+  }
   if (c < g.C) {
 #pragma unroll
     for (int t = 0; t < RS; ++t) {
@@ -765,6 +783,7 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
   const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
   const int splits = wgrad_splits(tiles, a.chunks);
   a.per_split = (a.chunks + splits - 1) / splits;
+  a.dw = dw; a.direct = splits == 1; a.accumulate = accumulate;
   hipStream_t st = salun_hip_stream(stream);
   int rc;
   if (R == 3 && stride == 1) rc = launch_wgrad<3, 1>(a, splits, st);
@@ -772,10 +791,12 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
   else if (stride == 1) rc = launch_wgrad<1, 1>(a, splits, st);
   else rc = launch_wgrad<1, 2>(a, splits, st);
   if (rc != SALUN_OK) return rc;
-  const int64_t kc = (int64_t)K * C;
-  hipLaunchKernelGGL(k_wgrad_reduce_bf16, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, st, a.part, dw, K, C, R * R,
-                     splits, accumulate);
-  SALUN_LAUNCH_CHECK();
+  if (!a.direct) {
+    const int64_t kc = (int64_t)K * C;
+    hipLaunchKernelGGL(k_wgrad_reduce_bf16, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, st, a.part, dw, K, C, R * R,
+                       splits, accumulate);
+    SALUN_LAUNCH_CHECK();
+  }
   if (db) {
     const int64_t M = (int64_t)N * OH * OW;
     int chunks = (int)((M + 63) / 64);

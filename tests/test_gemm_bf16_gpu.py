@@ -20,7 +20,7 @@ def rel(got, want):
     return float((got.double() - want.double()).abs().max() / want.double().abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 640, 320), (616, 1280, 768), (8192, 2560, 320), (77, 128, 1280)])
 def test_gemm_bf16_nt_matches_fp32_matmul_of_the_rounded_operands(variant, M, N, K):
     from unlearn_saliency_amd import ops
@@ -42,7 +42,7 @@ def test_gemm_bf16_nt_matches_fp32_matmul_of_the_rounded_operands(variant, M, N,
 def test_variants_agree_bitwise_and_shapes_outside_the_domain_are_refused():
     from unlearn_saliency_amd import _lib, ops
     x, w = dev((4096, 320), 5).bfloat16(), dev((640, 320), 6, 0.05).bfloat16()
-    outs = [ops.gemm_bf16_nt(x, w, None, None, v) for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)]
+    outs = [ops.gemm_bf16_nt(x, w, None, None, v) for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])  # same k order in every tile shape: identical fp32 sums
     assert not ops.gemm_bf16_supported(128, 96, 64) and not ops.gemm_bf16_supported(128, 64, 40)

@@ -21,7 +21,7 @@ def timeit(fn, reps):
     return best * 1e3  # us
 
 
-VARS = (1, 2, 3, 7, 8, 9, 10)
+VARS = (3, 8, 9, 10, 11, 12, 13)
 
 
 def main():
@@ -45,7 +45,7 @@ def main():
         row = f"{M:>6} {N:>6} {K:>5} | {t_lib:8.1f} {fl / t_lib / 1e6:6.0f} | "
         best = 1e9
         for v in VARS:
-            if v in (1, 2, 5, 7, 8, 10) and N % 128:
+            if v in (1, 2, 5, 7, 8, 10, 11, 12) and N % 128:
                 row += f"{'-':>8} {'-':>6} "
                 continue
             t = timeit(lambda: ops.gemm_bf16_nt(x, w, bias, None, v), a.reps)

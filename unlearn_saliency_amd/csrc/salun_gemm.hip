@@ -811,7 +811,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_p(const GbArgs 
 #define GB_WAIT_VM(N)                                                  \
   do {                                                                 \
     if constexpr ((N) == 0) __builtin_amdgcn_s_waitcnt(0x0f70);        \
+    else if constexpr ((N) == 3) __builtin_amdgcn_s_waitcnt(0x0f73);   \
     else if constexpr ((N) == 4) __builtin_amdgcn_s_waitcnt(0x0f74);   \
+    else if constexpr ((N) == 5) __builtin_amdgcn_s_waitcnt(0x0f75);   \
     else if constexpr ((N) == 6) __builtin_amdgcn_s_waitcnt(0x0f76);   \
     else if constexpr ((N) == 8) __builtin_amdgcn_s_waitcnt(0x0f78);   \
     else if constexpr ((N) == 10) __builtin_amdgcn_s_waitcnt(0x0f7a);  \
@@ -821,16 +823,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_p(const GbArgs 
     else static_assert((N) < 0, "add the literal encoding of this vmcnt"); \
   } while (0)
 
-template <int WGM, int WGN, int NST>
-__global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_r(const GbArgs g) {
+// BK = 64: 128-byte rows, 8 lanes per row in a DMA unit, chunk swizzle (row >> 1) & 7.  BK = 32: 64-byte rows, 4 lanes per
+// row, swizzle (row >> 2) & 3 (16 consecutive rows of one chunk column then cover the 64 banks exactly once) — half the
+// LDS per stage, so TWO workgroups fit a CU: with K = 320 .. 640 a tile is only 5 .. 10 k-steps long and a lone
+// workgroup spends as long filling its ring and writing its result as multiplying (r04 counters: matrix pipes busy 26 %,
+// LDS 21 %, waves parked on waits 43 % — profiles/r04_gemm_sq_pmc_*.csv); a second resident workgroup multiplies meanwhile.
+template <int WGM, int WGN, int NST, int BK>
+__global__ __launch_bounds__(64 * WGM * WGN, (BK == 32 && WGM * WGN == 8) ? 4 : 1) void k_gemm_bf16_nt_r(const GbArgs g) {
   constexpr int NW = WGM * WGN;
   constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
   constexpr int ROWS = BMt + BNt;
-  constexpr int STAGE = ROWS * 128;
-  constexpr int IPW = ROWS / 8 / NW;
+  constexpr int ROWB = BK * 2;           // bytes per staged row
+  constexpr int LPR = BK / 8;            // lanes (16-byte chunks) per row
+  constexpr int RPU = 64 / LPR;          // rows per 1 KB DMA unit
+  constexpr int STAGE = ROWS * ROWB;
+  constexpr int IPW = ROWS / RPU / NW;
+  constexpr int KK = BK / 16;
   constexpr int EROW = 64 * 4 + 16;  // epilogue row: 64 fp32 features + pad (16-byte aligned, spreads the banks)
-  static_assert(ROWS % (8 * NW) == 0 && NST >= 3 && NST <= 4, "tile");
-  static_assert(NW * 64 * EROW <= NST * STAGE, "epilogue staging fits the ring");
+  constexpr int EP = (NW * 64 * EROW <= NST * STAGE) ? 1 : 2;   // passes of the epilogue staging (64 or 32 tokens per wave)
+  static_assert(ROWS % (RPU * NW) == 0 && NST >= 3 && NST <= 4 && (BK == 64 || BK == 32), "tile");
+  static_assert(NW * (64 / EP) * EROW <= NST * STAGE, "epilogue staging fits the ring");
   static_assert(IPW * (NST - 2) < 64, "vmcnt range");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
 
@@ -854,8 +866,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_r(const GbArgs 
   const uint16_t *src[IPW];
 #pragma unroll
   for (int i = 0; i < IPW; ++i) {
-    const int rr = 8 * (wave * IPW + i) + (lane >> 3);
-    const int c = (lane & 7) ^ ((rr >> 1) & 7);
+    const int rr = RPU * (wave * IPW + i) + lane / LPR;
+    const int c = (BK == 64) ? ((lane & 7) ^ ((rr >> 1) & 7)) : ((lane & 3) ^ ((rr >> 2) & 3));
     int m = m0 + rr;
     if (m > g.M - 1) m = g.M - 1;
     const uint16_t *px = g.x + (size_t)m * g.K + c * 8;
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_r(const GbArgs 
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       lds_ptr_t d = (lds_ptr_t)(lds + buf * STAGE + (wave * IPW + i) * 1024);
-      const uint16_t *p = src[i] + ks * 64;
+      const uint16_t *p = src[i] + ks * BK;
       __builtin_amdgcn_global_load_lds(p, d, 16, 0, 0);
     }
   };
@@ -879,21 +891,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_r(const GbArgs 
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
-  const int sw = (lo >> 1) & 7;
-  const int x_row = (wm * 64 + lo) * 128;
-  const int w_row = (BMt + wn * 64 + lo) * 128;
-  int ch[4];
+  const int sw = (BK == 64) ? ((lo >> 1) & 7) : ((lo >> 2) & 3);
+  const int x_row = (wm * 64 + lo) * ROWB;
+  const int w_row = (BMt + wn * 64 + lo) * ROWB;
+  int ch[KK];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) ch[kk] = ((2 * kk + hi) ^ sw) * 16;
+  for (int kk = 0; kk < KK; ++kk) ch[kk] = ((2 * kk + hi) ^ sw) * 16;
 
   auto compute = [&](int buf) {
     const char *base = lds + buf * STAGE;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KK; ++kk) {
       const g_bf16x8 w0 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + ch[kk]);
-      const g_bf16x8 w1 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + 32 * 128 + ch[kk]);
+      const g_bf16x8 w1 = *reinterpret_cast<const g_bf16x8 *>(base + w_row + 32 * ROWB + ch[kk]);
       const g_bf16x8 x0 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + ch[kk]);
-      const g_bf16x8 x1 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + 32 * 128 + ch[kk]);
+      const g_bf16x8 x1 = *reinterpret_cast<const g_bf16x8 *>(base + x_row + 32 * ROWB + ch[kk]);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
@@ -901,7 +913,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_r(const GbArgs 
     }
   };
 
-  const int nk = g.K >> 6;
+  const int nk = g.K / BK;
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) issue(s0, s0);
@@ -919,20 +931,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_r(const GbArgs 
     nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
   }
 
-  // ---- epilogue through LDS: wave-private region, [token 64][feature 64] fp32 rows of EROW bytes
+  // ---- epilogue through LDS: wave-private region, [token 64 / EP][feature 64] fp32 rows of EROW bytes
   __builtin_amdgcn_s_barrier();  // all waves are done with the stage buffers
-  char *er = lds + wave * (64 * EROW);
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        // D[i = feature][j = token]: lane (token lo, half hi), registers 4q..4q+3: features 8q + 4hi + 0..3
-        float4 v4 = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
-        *reinterpret_cast<float4 *>(er + (b * 32 + lo) * EROW + (a * 32 + 8 * q + 4 * hi) * 4) = v4;
-      }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (wave-private region: no barrier)
+  char *er = lds + wave * ((64 / EP) * EROW);
   const int fr = (lane & 7) * 8;       // 8 features per lane, 8 lanes per token row
   float bsv[8];
 #pragma unroll
@@ -943,40 +944,57 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_bf16_nt_r(const GbArgs 
     bsv[0] = b0.x; bsv[1] = b0.y; bsv[2] = b0.z; bsv[3] = b0.w; bsv[4] = b1.x; bsv[5] = b1.y; bsv[6] = b1.z; bsv[7] = b1.w;
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int trow = i * 8 + (lane >> 3);
-    const int m = m0 + wm * 64 + trow;
-    const float4 u0 = *reinterpret_cast<const float4 *>(er + trow * EROW + fr * 4);
-    const float4 u1 = *reinterpret_cast<const float4 *>(er + trow * EROW + fr * 4 + 16);
-    if (m < g.M) {
-      float o[8] = {u0.x + bsv[0], u0.y + bsv[1], u0.z + bsv[2], u0.w + bsv[3],
-                    u1.x + bsv[4], u1.y + bsv[5], u1.z + bsv[6], u1.w + bsv[7]};
-      const size_t e = (size_t)m * g.N + n0 + wn * 64 + fr;
-      if (g.addend) {
-        const uint4 av = *reinterpret_cast<const uint4 *>(g.addend + e);
-        o[0] += gb_lo(av.x); o[1] += gb_hi(av.x); o[2] += gb_lo(av.y); o[3] += gb_hi(av.y);
-        o[4] += gb_lo(av.z); o[5] += gb_hi(av.z); o[6] += gb_lo(av.w); o[7] += gb_hi(av.w);
-      }
-      *reinterpret_cast<uint4 *>(g.y + e) = make_uint4(gb_pack2(o[0], o[1]), gb_pack2(o[2], o[3]), gb_pack2(o[4], o[5]),
-                                                       gb_pack2(o[6], o[7]));
+  for (int pass = 0; pass < EP; ++pass) {
+#pragma unroll
+    for (int bb = 0; bb < 2 / EP; ++bb) {
+      const int b = (EP == 2) ? pass : bb;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // D[i = feature][j = token]: lane (token lo, half hi), registers 4q..4q+3: features 8q + 4hi + 0..3
+          float4 v4 = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+          *reinterpret_cast<float4 *>(er + (bb * 32 + lo) * EROW + (a * 32 + 8 * q + 4 * hi) * 4) = v4;
+        }
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (wave-private region: no barrier)
+#pragma unroll
+    for (int i = 0; i < 8 / EP; ++i) {
+      const int trow = i * 8 + (lane >> 3);
+      const int m = m0 + wm * 64 + pass * 32 + trow;
+      const float4 u0 = *reinterpret_cast<const float4 *>(er + trow * EROW + fr * 4);
+      const float4 u1 = *reinterpret_cast<const float4 *>(er + trow * EROW + fr * 4 + 16);
+      if (m < g.M) {
+        float o[8] = {u0.x + bsv[0], u0.y + bsv[1], u0.z + bsv[2], u0.w + bsv[3],
+                      u1.x + bsv[4], u1.y + bsv[5], u1.z + bsv[6], u1.w + bsv[7]};
+        const size_t e = (size_t)m * g.N + n0 + wn * 64 + fr;
+        if (g.addend) {
+          const uint4 av = *reinterpret_cast<const uint4 *>(g.addend + e);
+          o[0] += gb_lo(av.x); o[1] += gb_hi(av.x); o[2] += gb_lo(av.y); o[3] += gb_hi(av.y);
+          o[4] += gb_lo(av.z); o[5] += gb_hi(av.z); o[6] += gb_lo(av.w); o[7] += gb_hi(av.w);
+        }
+        *reinterpret_cast<uint4 *>(g.y + e) = make_uint4(gb_pack2(o[0], o[1]), gb_pack2(o[2], o[3]), gb_pack2(o[4], o[5]),
+                                                         gb_pack2(o[6], o[7]));
+      }
+    }
+    if (EP == 2 && pass == 0) __builtin_amdgcn_s_waitcnt(0xc07f);  // the rows are read before the second half overwrites them
   }
 }
 
-template <int WGM, int WGN, int NST>
+template <int WGM, int WGN, int NST, int BK = 64>
 int launch_gemm_bf16_r(const GbArgs &g0, hipStream_t st) {
   GbArgs g = g0;
   constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
   g.tiles_m = (g.M + BMt - 1) / BMt;
   g.tiles_n = g.N / BNt;
-  const size_t ldsb = (size_t)NST * (BMt + BNt) * 128;
+  const size_t ldsb = (size_t)NST * (BMt + BNt) * BK * 2;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt_r<WGM, WGN, NST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt_r<WGM, WGN, NST, BK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     configured = true;
   }
-  hipLaunchKernelGGL((k_gemm_bf16_nt_r<WGM, WGN, NST>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
+  hipLaunchKernelGGL((k_gemm_bf16_nt_r<WGM, WGN, NST, BK>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }
@@ -1322,10 +1340,11 @@ SALUN_EXPORT int salun_gemm_bf16_nt(const void *x, const void *w, const float *b
   g.M = (int)M; g.N = N; g.K = K; g.tiles_m = g.tiles_n = 0;
   hipStream_t st = salun_hip_stream(stream);
   if (variant == 0) {
-    // measured on the SD shapes (profiles/r04_gemmbench_bf16.txt): the 8-wave 256 x 128 ring wins wherever it has >= ~128
-    // tiles; the 4-wave 128 x 128 ring on smaller problems; feature counts that are multiples of 64 only: 256 x 64
-    if (N % 128 != 0) variant = 3;
-    else variant = (((M + 255) / 256) * (int64_t)(N / 128) >= 128) ? 8 : 10;
+    // measured on the SD shapes (profiles/r04_gemmbench_bf16.txt): the 8-wave 256 x 128 ring with 32-deep stages (two
+    // workgroups per CU) wins wherever it has >= ~128 tiles; the 4-wave 128 x 128 ring on smaller problems; feature counts
+    // that are multiples of 64 only: 256 x 64, 32-deep
+    if (N % 128 != 0) variant = 13;
+    else variant = (((M + 255) / 256) * (int64_t)(N / 128) >= 128) ? 11 : 10;
   }
   if ((variant == 1 || variant == 2) && N % 128 != 0) return SALUN_EINVAL;
   switch (variant) {
@@ -1339,6 +1358,9 @@ SALUN_EXPORT int salun_gemm_bf16_nt(const void *x, const void *w, const float *b
     case 8: return (N % 128 == 0) ? launch_gemm_bf16_r<4, 2, 3>(g, st) : SALUN_EINVAL;   // 256 x 128, 8 waves, 3 stages (144 KB)
     case 9: return launch_gemm_bf16_r<4, 1, 3>(g, st);                                   // 256 x 64, 3 stages (120 KB)
     case 10: return (N % 128 == 0) ? launch_gemm_bf16_r<2, 2, 3>(g, st) : SALUN_EINVAL;  // 128 x 128, 3 stages (96 KB)
+    case 11: return (N % 128 == 0) ? launch_gemm_bf16_r<4, 2, 3, 32>(g, st) : SALUN_EINVAL;  // 256 x 128, 32-deep stages (72 KB: two per CU)
+    case 12: return (N % 128 == 0) ? launch_gemm_bf16_r<2, 2, 4, 32>(g, st) : SALUN_EINVAL;  // 128 x 128, 32-deep x 4 (64 KB: two per CU)
+    case 13: return launch_gemm_bf16_r<4, 1, 3, 32>(g, st);                                  // 256 x 64, 32-deep (60 KB: two per CU)
     default: return SALUN_EINVAL;
   }
 }

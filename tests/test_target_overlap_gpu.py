@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from fixtures import ddpm_batch, ddpm_small_config, fill_params, sd_tiny_config
-from unlearn_saliency_amd import rng
+from unlearn_saliency_amd import draws, rng
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +37,7 @@ def _ddpm_run(overlap, monkeypatch):
     r.config, r.device, r.num_timesteps = cfg, torch.device("cuda"), 1000
     r.betas = torch.linspace(1e-4, 0.02, 1000, device="cuda")
     torch.manual_seed(99)
+    draws.seed(None)  # dropout keys = f(torch seed, step, call): both runs start at step 0
     losses = []
     for step in range(3):
         rb = tuple(torch.from_numpy(np.ascontiguousarray(v)).cuda() for v in ddpm_batch(4, 300 + step))

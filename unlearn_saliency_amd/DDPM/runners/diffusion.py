@@ -128,6 +128,7 @@ class Diffusion(object):
         self.args, self.config = args, config
         if not torch.cuda.is_available():
             raise RuntimeError("the DDPM hot path needs a ROCm device (no CPU fallback)")
+        draws.seed(None)  # a run's dropout keys restart from (torch seed, step 0): main.py seeds torch before this
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.model_var_type = config.model.var_type
         betas = get_beta_schedule(beta_schedule=config.diffusion.beta_schedule,

@@ -146,7 +146,7 @@ def test_attention_f32_matches_float64_in_both_layouts(layout, B, H, Tq, Tk, D):
 
     q, k, v = (mk(Tq, 41).requires_grad_(True), mk(Tk, 42).requires_grad_(True), mk(Tk, 43).requires_grad_(True))
     scale = D ** -0.5
-    assert gemm.attention_supported(q, k, v)
+    assert gemm.attention_supported(q, k, v) == (Tq * Tk <= gemm.ATTENTION_MAX_SCORES)  # the model-side routing rule
     o = gemm.attention_f32(q, k, v, scale)
     assert o.stride() == q.stride()  # written in the caller's layout: no transposing copy on the way back
     do = mk(Tq, 44)

@@ -1,7 +1,9 @@
 """Turn the per-kernel PMC tables of tools/pmc.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, SEPARATE passes) into
 HBM bytes per launch next to the algorithmic bytes.
 
-    python tools/pmc_traffic.py <tag>:<N> [<tag>:<N> ...] > profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py <tag>:<N> [<tag>:<N> ...] [<tag>:<kernel substring>=<algorithmic bytes> ...] > profiles/rNN_pmc_traffic.json
+
+(the second form: any kernel of a table by name, with the algorithmic bytes of one launch given by the caller)
 
 reads gpurun_out/<tag>_FETCH_SIZE.csv and gpurun_out/<tag>_WRITE_SIZE.csv.  Units: rocprofv3 reports KiB; FETCH_SIZE
 is doubled for wide coalesced reads on gfx950 (MI355X_MICROARCH.md §HBM).  The top-k is reported per CALL (sum over its
@@ -28,7 +30,20 @@ def main():
                    "doubled per MI355X_MICROARCH.md §HBM (gfx950 wide coalesced reads); top-k figures are per CALL of "
                    "salun_mask_topk (one threshold), summed over its kernels", "kernels": {}}
     for spec in sys.argv[1:]:
-        tag, n = spec.split(":")
+        tag, n = spec.split(":", 1)
+        if "=" in n:
+            kern, alg = n.split("=")
+            alg = float(alg)
+            f = table(os.path.join(HERE, "gpurun_out", f"{tag}_FETCH_SIZE.csv"))
+            w = table(os.path.join(HERE, "gpurun_out", f"{tag}_WRITE_SIZE.csv"))
+            fk = [k for k in f if kern in k]
+            wk = [k for k in w if kern in k]
+            if fk and wk:
+                rd, wr = 2 * f[fk[0]][1] * 1024, w[wk[0]][1] * 1024
+                res["kernels"][f"{kern}@{tag}"] = {"fetch_size_kib_raw": f[fk[0]][1], "write_size_kib_raw": w[wk[0]][1],
+                                                   "read_bytes_corrected": rd, "write_bytes": wr, "traffic_bytes": rd + wr,
+                                                   "algorithmic_bytes": alg, "traffic_over_algorithmic": (rd + wr) / alg}
+            continue
         n = int(n)
         f = table(os.path.join(HERE, "gpurun_out", f"{tag}_FETCH_SIZE.csv"))
         w = table(os.path.join(HERE, "gpurun_out", f"{tag}_WRITE_SIZE.csv"))

@@ -19,6 +19,8 @@ Weight / bias gradients are accumulated by the kernels straight into the paramet
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 from typing import List, Optional, Sequence, Tuple
 
@@ -130,9 +132,20 @@ def softmax_rows_backward_(p: torch.Tensor, dp: torch.Tensor, scale: float) -> t
 
 
 # ----------------------------------------------------------------------------------------------- Linear
+# Where K15 is used.  It is a compact kernel (64 / 128-square tiles, 16-deep register-staged chunks) whose value is what it
+# fuses — 22 embedding projections in one launch, an attention whose operands stay in the caller's layout, gradients added
+# straight into the flat arena — on the small and medium problems of the DDPM U-Net.  On the plain multi-GFLOP products of
+# the fp32 SD configuration the library GEMM is 1.5x faster (profiles/r04_gemmbench_f32.txt: 83-87 vs 128-140 TFLOP/s, the
+# weight-gradient orientation 37-62 vs 55-116; whole step 1070 ms on K15 vs 765 ms), so those stay library GEMMs, and an
+# attention whose score matrix passes 512 x 512 per head goes to the library's fused attention instead of materialising it.
+LINEAR_MAX_FLOP = float(os.environ.get("SALUN_K15_MAX_GFLOP", "1.0")) * 1e9
+ATTENTION_MAX_SCORES = 512 * 512
+
+
 def _eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_cuda
-            and not torch.is_autocast_enabled() and x.shape[-1] == weight.shape[1] and x.numel() > 0)
+            and not torch.is_autocast_enabled() and x.shape[-1] == weight.shape[1] and x.numel() > 0
+            and 2.0 * x.numel() * weight.shape[0] <= LINEAR_MAX_FLOP)
 
 
 class _Linear(torch.autograd.Function):
@@ -353,4 +366,5 @@ def attention_f32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: floa
 
 def attention_supported(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
     return (all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and (t.stride(2) == 1 or t.stride(3) == 1)
-                for t in (q, k, v)) and not torch.is_autocast_enabled() and q.shape[0] * q.shape[1] <= 65535)
+                for t in (q, k, v)) and not torch.is_autocast_enabled() and q.shape[0] * q.shape[1] <= 65535
+            and q.shape[2] * k.shape[2] <= ATTENTION_MAX_SCORES)

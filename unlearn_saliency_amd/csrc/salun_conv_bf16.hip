@@ -730,7 +730,9 @@ extern "C" int salun_gemm_bf16_tn(const void *dy, const void *x, float *dw, int6
                                   void *ws, size_t ws_bytes, salun_stream_t stream);
 static bool tn_route(int64_t M, int C, int K, int R, int stride, int pad) {
   static const int on = [] { const char *e = getenv("SALUN_WGRAD_TN"); return e ? atoi(e) : 1; }();
-  return on && R == 1 && stride == 1 && pad == 0 && salun_gemm_bf16_tn_supported(M, K, C);
+  // short reductions (the 8 x 8 level: M = 512) keep the tap kernel: with one split it adds straight into the gradient,
+  // the GEMM would need partials there (profiles/r04_gemmbench_bf16.txt: 11.6 vs 17.5 us, 51 vs 61 us)
+  return on && R == 1 && stride == 1 && pad == 0 && M >= 1024 && salun_gemm_bf16_tn_supported(M, K, C);
 }
 
 SALUN_EXPORT size_t salun_conv2d_bf16_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad) {

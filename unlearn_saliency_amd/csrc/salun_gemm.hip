@@ -1020,6 +1020,7 @@ struct TnArgs {
   int M, Na, Nb;
   int tiles_a, tiles_b;
   int stages, per_split;  // stages of RST tokens in total / per split
+  int nsplit;
   int accumulate;         // splits == 1 only: dW += instead of dW =
 };
 
@@ -1094,15 +1095,21 @@ __global__ __launch_bounds__(64 * WGA * WGB) void k_gemm_bf16_tn(const TnArgs g)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave % WGA, wb = wave / WGA;
+  // One linear grid over (split, tile), split-major: consecutive work items are the tiles of ONE token range, and an XCD
+  // (workgroup id & 7) takes a contiguous run of them — the b-tiles that share a dY column block then share that XCD's
+  // L2.  (With the split on blockIdx.y the hardware's id -> XCD mapping no longer matched the remap for y > 0 and dY
+  // came from memory once per b-tile: 446 MB against 197 MB algorithmic, profiles/r04_pmc_traffic.json before the change.)
   const int ntile = g.tiles_a * g.tiles_b;
-  int tile;
+  int work;
   {
-    const int id = blockIdx.x, xcd = id & 7, q = ntile >> 3, r = ntile & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    const int total = ntile * g.nsplit;
+    const int id = blockIdx.x, xcd = id & 7, q = total >> 3, r = total & 7;
+    work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
+  const int split = work / ntile;
+  const int tile = work - split * ntile;
   const int ta = tile / g.tiles_b, tb = tile - ta * g.tiles_b;
   const int a0 = ta * TA, b0 = tb * TB;
-  const int split = blockIdx.y;
   const int sb = split * g.per_split;
   const int se = min(g.stages, sb + g.per_split);
   const int nk = se - sb;
@@ -1242,7 +1249,7 @@ int launch_gemm_bf16_tn(const TnArgs &g, int splits, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     configured = true;
   }
-  hipLaunchKernelGGL((k_gemm_bf16_tn<WGA, WGB, RST, NST>), dim3(g.tiles_a * g.tiles_b, splits), dim3(64 * WGA * WGB), ldsb, st, g);
+  hipLaunchKernelGGL((k_gemm_bf16_tn<WGA, WGB, RST, NST>), dim3(g.tiles_a * g.tiles_b * splits), dim3(64 * WGA * WGB), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }
@@ -1389,7 +1396,7 @@ SALUN_EXPORT int salun_gemm_bf16_tn(const void *dy, const void *x, float *dw, in
   g.dy = static_cast<const uint16_t *>(dy); g.x = static_cast<const uint16_t *>(x);
   g.out = p.splits > 1 ? static_cast<float *>(ws) : dw;
   g.M = (int)M; g.Na = Na; g.Nb = Nb; g.tiles_a = p.tiles_a; g.tiles_b = p.tiles_b;
-  g.stages = p.stages; g.per_split = p.per_split; g.accumulate = (p.splits == 1 && accumulate) ? 1 : 0;
+  g.stages = p.stages; g.per_split = p.per_split; g.nsplit = p.splits; g.accumulate = (p.splits == 1 && accumulate) ? 1 : 0;
   hipStream_t st = salun_hip_stream(stream);
   int rc;
   if (p.variant == 1) rc = launch_gemm_bf16_tn<2, 2, 64, 3>(g, p.splits, st);

@@ -428,6 +428,8 @@ def main():
         with sync_free(opt):
             criterion(model(xs), ys).backward()
         arena.zero_grad()  # discard: no parameter update from the shape warm-up
+    from unlearn_saliency_amd import hostperf
+    hostperf.freeze_gc()  # as the unlearning epoch driver does before its first epoch (unlearn/impl.py)
     for _ in range(a.warmup):
         one_step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]

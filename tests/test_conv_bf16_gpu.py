@@ -25,6 +25,12 @@ SHAPES = [
     (8, 16, 16, 640, 640, 3, 2, 1),
     (2, 64, 64, 320, 320, 3, 1, 1),    # full 64x64 latent extent
     (8, 8, 8, 2560, 1280, 3, 1, 1),    # decoder entry (concatenated skip)
+    # shapes with >= 128 forward tiles: the 1x1 one takes the LDS-DMA ring kernel (k_conv_bf16_ring, salun_gemm.hip) by
+    # default, all four do under SALUN_CONV_RING=3 (test_ring_kernel_every_tile_form_in_a_child_process)
+    (4, 64, 64, 32, 256, 3, 1, 1),     # 256 x 128 tiles
+    (4, 64, 64, 64, 256, 1, 1, 0),     # 256 x 128, 1x1
+    (5, 62, 62, 64, 192, 3, 1, 1),     # 256 x 64 tiles, ragged last pixel tile
+    (4, 128, 128, 32, 128, 3, 2, 1),   # 128 x 128 tiles, stride 2
 ]
 
 
@@ -87,6 +93,27 @@ def test_epilogue_terms():
     addx = _mk((N, H, W, C), 8)
     dx1 = ops.conv2d_bf16_backward_data(dy, wp, (N, H, W, C), 3, 1, 1, addend=addx)
     _close_bf16(dx1, dx_ref.permute(0, 2, 3, 1) + addx.float(), "backward-data + addend")
+
+
+def test_ring_kernel_every_tile_form_in_a_child_process():
+    """SALUN_CONV_RING=3 sends every eligible forward launch (>= 128 tiles) to the LDS-DMA ring kernel (by default only the
+    1x1 convolutions go there: the 3x3 ones are faster on the register-staged kernel); the switch is read once per process,
+    so the 3x3 / stride-2 / ragged shapes of SHAPES and the epilogue terms are re-run in a child."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, torch; sys.path.insert(0, %r); import test_conv_bf16_gpu as t\n"
+            "from unlearn_saliency_amd import ops\n"
+            "for sh in t.SHAPES[-4:] + [(8, 32, 32, 320, 320, 3, 1, 1), (8, 16, 16, 640, 1280, 3, 1, 1)]:\n"
+            "    t.test_forward_backward_match_library_on_bf16_inputs(sh)\n"
+            "N,H,W,C,K=4,64,64,64,256; x=t._mk((N,H,W,C),5); w=torch.randn(K,C,3,3,device='cuda')/24.0\n"
+            "wp=ops.conv2d_bf16_pack(w); bias=torch.randn(K,device='cuda'); nb=torch.randn(N,K,device='cuda'); add=t._mk((N,H,W,K),6)\n"
+            "base=torch.nn.functional.conv2d(x.float().permute(0,3,1,2), w.to(torch.bfloat16).float(), bias, 1, 1).permute(0,2,3,1)\n"
+            "y=ops.conv2d_bf16_forward(x,wp,3,1,1,bias=bias,nbias=nb,addend=add)\n"
+            "t._close_bf16(y, base + nb[:,None,None,:] + add.float(), 'ring forward + bias + nbias + addend')\n"
+            "print('ring ok')") % here
+    env = dict(os.environ, SALUN_CONV_RING="3", PYTHONPATH=os.path.dirname(here))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ring ok"), out.stderr[-3000:]
 
 
 def test_unsupported_shapes_are_refused():

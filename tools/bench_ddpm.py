@@ -147,6 +147,8 @@ def main(argv=None):
     opt.set_mask(mask)
     model.train()
     ri, fi = cycle(remain_loader), cycle(forget_loader)
+    from unlearn_saliency_amd import hostperf
+    hostperf.freeze_gc()  # as Diffusion.saliency_unlearn does before its first step
     for _ in range(a.warmup):
         runner.unlearn_step(model, opt, next(ri), next(fi))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]

@@ -137,6 +137,8 @@ def main(argv=None):
     from unlearn_saliency_amd.optim import FusedMaskedAdam
     run.opt = FusedMaskedAdam(arena, lr=1e-5)
     run.opt.set_mask(m)
+    from unlearn_saliency_amd import hostperf
+    hostperf.freeze_gc()  # what the training loops of train_scripts.py do before their first step
     run(a.warmup)
     graph_note = None
     if a.graph:

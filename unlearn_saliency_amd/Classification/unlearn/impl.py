@@ -22,6 +22,7 @@ from typing import Dict, Optional
 
 import torch
 
+from ... import hostperf
 from ...flat import arena_of
 from ...optim import FusedMaskedSGD
 from .. import utils
@@ -69,6 +70,7 @@ def _iterative_unlearn_impl(unlearn_iter_func):
             optimizer.set_mask(arena.pack_mask(mask))
         scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=milestones, gamma=0.1)
         try:
+            hostperf.freeze_gc()
             for epoch in range(0, args.unlearn_epochs):
                 start_time = time.time()
                 print("Epoch #{}, Learning rate: {}".format(epoch, optimizer.param_groups[0]["lr"]))

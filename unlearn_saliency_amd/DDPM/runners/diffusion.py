@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from ... import dist as sdist
-from ... import draws, ops
+from ... import draws, hostperf, ops
 from ...flat import FlatArena, arena_of
 from ..datasets import data_transform, get_forget_dataset
 from ..functions import cycle, get_optimizer
@@ -180,6 +180,7 @@ class Diffusion(object):
         acc = arena.new_like()
         sq = torch.zeros(1, device=self.device)
         model.eval()
+        hostperf.freeze_gc()
         ws = sdist.world_size()
         for x, forget_c in forget_loader:
             n = x.size(0)
@@ -307,6 +308,7 @@ class Diffusion(object):
         self.last_optimizer = optimizer
         self.step_losses = []  # device scalars of the last `keep_losses` steps (no host sync; diagnostics / parity tests)
         keep_losses = int(getattr(args, "keep_losses", 64))
+        hostperf.freeze_gc()
         for step in range(0, config.training.n_iters):
             model.train()
             loss = self.unlearn_step(model, optimizer, next(remain_iter), next(forget_iter))
@@ -408,6 +410,7 @@ class Diffusion(object):
                 fisher_dict = pickle.load(f)
         fisher_flat = arena.pack(strip_prefix(fisher_dict))
         params_mle_flat = arena.params.clone()
+        hostperf.freeze_gc()
         for step in range(0, config.training.n_iters):
             model.train()
             loss, forgetting_loss, ewc_loss = self.forget_step(model, optimizer, next(remember_iter), fisher_flat,

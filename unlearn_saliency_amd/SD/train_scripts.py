@@ -23,7 +23,7 @@ import torch
 import yaml
 
 from .. import dist as sdist
-from .. import draws, ops
+from .. import draws, hostperf, ops
 from ..flat import FlatArena
 from ..optim import FusedMaskedAdam
 from .ldm_lite import SD_V1_FROZEN_PARAMS, LatentDiffusionLite  # noqa: F401 (re-exported)
@@ -87,6 +87,7 @@ def _saliency_mask(model, batches, c_guidance, mask_path, ratio=0.5):
     arena = _unet_arena(model)
     acc = arena.new_like()
     model.eval()
+    hostperf.freeze_gc()
     for z, c_forget, c_null in batches:
         z, c_forget, c_null = z.to(model.device), c_forget.to(model.device), c_null.to(model.device)
         sh = draws.shard_of(batches, z.shape[0])
@@ -190,6 +191,7 @@ def _unlearn(model, forget_dl, remain_dl, alpha, epochs, lr, mask_path, train_me
     towards their initial values so that `ratio_t` of them are reset exactly (one diff + select + threshold pass over
     the flat arena, K9)."""
     arena = _unet_arena(model)
+    hostperf.freeze_gc()
     init_params = arena.params.clone() if proximal_ratio is not None else None
     # the reference ranks over the whole LatentDiffusion: U-Net + the frozen first stage and text encoder
     n_frozen = int(getattr(model, "frozen_param_count", 0)) if proximal_ratio is not None else 0

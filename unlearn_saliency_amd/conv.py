@@ -13,6 +13,8 @@ from __future__ import annotations
 import os
 
 import torch
+
+from .fastfn import FastFunction
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -58,7 +60,7 @@ def _eligible(mod: nn.Conv2d) -> bool:
             and mod.padding_mode == "zeros" and mod.weight.dtype == torch.float32)
 
 
-class _ConvFn(torch.autograd.Function):
+class _ConvFn(FastFunction):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, P, Q):
         y = ops.conv2d_forward(x, w, bias, stride, pad, P, Q)

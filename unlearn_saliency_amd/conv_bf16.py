@@ -17,6 +17,8 @@ run on the fp32 MFMA kernels of conv.py; nothing here calls the library convolut
 from __future__ import annotations
 
 import torch
+
+from .fastfn import FastFunction
 import torch.nn as nn
 
 from . import gradsink, ops
@@ -28,7 +30,7 @@ def _nhwc(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
 
 
-class _ConvBF16Fn(torch.autograd.Function):
+class _ConvBF16Fn(FastFunction):
     @staticmethod
     def forward(ctx, x, w, bias, mod, nbias, addend):
         R, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
@@ -119,7 +121,7 @@ _USE_K16 = [_os.environ.get("SALUN_LINEAR_GEMM", "1") != "0"]
 _K16_VARIANT = [int(_os.environ.get("SALUN_LINEAR_GEMM_VARIANT", "0"))]
 
 
-class _LinearBF16Fn(torch.autograd.Function):
+class _LinearBF16Fn(FastFunction):
     """y = x W^T + b (+ addend) on bf16 tokens.  Forward and input gradient: K16 (csrc/salun_gemm.hip, direct-to-LDS
     GEMM on the [N, K] / [K, N] weight images) when the feature counts are multiples of 64, else the K11 1x1
     convolution kernels; weight / bias gradients: K11 backward-weight, added in fp32 into the flat gradient."""

@@ -692,6 +692,10 @@ SALUN_EXPORT size_t salun_conv2d_bf16_data_workspace_bytes(int N, int H, int W, 
   return need;
 }
 
+extern "C" int salun_conv2d_bf16_forward_ring(const uint16_t *x, const uint16_t *wp, const float *bias, const float *nbias,
+                                              const uint16_t *addend, uint16_t *y, int N, int H, int W, int C, int K, int R,
+                                              int stride, int pad, hipStream_t st);
+
 SALUN_EXPORT int salun_conv2d_bf16_forward(const uint16_t *x, const uint16_t *wp, const float *bias, const float *nbias,
                                            const uint16_t *addend, uint16_t *y, int N, int H, int W, int C, int K, int R,
                                            int stride, int pad, void *ws, size_t ws_bytes, salun_stream_t stream) {
@@ -702,6 +706,11 @@ SALUN_EXPORT int salun_conv2d_bf16_forward(const uint16_t *x, const uint16_t *wp
     return SALUN_EINVAL;
   // the staging addresses use 24-bit multiplies: pixel counts and channel counts below 2^24
   if ((int64_t)N * H * W >= (1 << 24) || (int64_t)N * OH * OW >= (1 << 24) || C >= (1 << 24) || K >= (1 << 24)) return SALUN_EINVAL;
+  {  // the LDS-DMA ring form (salun_gemm.hip) where the launch has enough tiles to do without a reduction split
+    const int rc = salun_conv2d_bf16_forward_ring(x, wp, bias, nbias, addend, y, N, H, W, C, K, R, stride, pad,
+                                                  salun_hip_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : SALUN_OK;
+  }
   IgArgs a{x, wp, bias, nbias, addend, y, N * OH * OW, H, W, C, OH, OW, K, R, stride, pad, 1, K, C, nullptr, 0};
   return dispatch_igemm<false>(a, ws, ws_bytes, salun_hip_stream(stream));
 }

@@ -24,6 +24,7 @@
 // split the reduction over blockIdx.z into fp32 partial images that a second kernel folds in a fixed order (no float
 // atomics anywhere: results are deterministic).
 #include "salun_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -999,6 +1000,227 @@ int launch_gemm_bf16_r(const GbArgs &g0, hipStream_t st) {
   return SALUN_OK;
 }
 
+// ------------------------------------------------------------------------------------------- K16 ring as a convolution
+// The same ring with the A rows GATHERED: row m of the implicit GEMM is output pixel m, and for reduction stage
+// (tap (r, s), 32 input channels from c0) its 64 bytes are x[n][oh*stride - pad + r][ow*stride - pad + s][c0 .. c0+31] of
+// an NHWC tensor — or zeros outside the image.  LDS-DMA takes a per-lane source address, so the gather costs nothing
+// extra: the per-pixel base pointer and a 9-bit validity mask are fixed before the loop, the (tap, c0) offset is
+// wave-uniform, invalid rows read a 16-byte zero word.  Weight rows come from the packed image wp[K][R*R][C].  Output
+// y[m][k] (NHWC) = sum + bias[k] + nbias[n][k] + addend[m][k], rounded once to bf16 (the epilogues of K11's forward,
+// reference SD openaimodel.py ResBlock: `h + emb_out[..., None, None]`, skip `x + h`).
+__device__ uint4 g_tn_zero = {0u, 0u, 0u, 0u};
+
+struct IrArgs {
+  const uint16_t *x;       // [N][H][W][Cin] bf16
+  const uint16_t *wp;      // [Kout][R*R][Cin] bf16
+  const float *bias;       // [Kout] or null
+  const float *nbias;      // [N][Kout] or null
+  const uint16_t *addend;  // [M][Kout] bf16 or null
+  uint16_t *y;             // [M][Kout] bf16
+  int M, H, W, Cin, OH, OW, Kout, R, stride, pad;
+  int tiles_m, tiles_n;
+};
+
+template <int WGM, int WGN, int NST>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_conv_bf16_ring(const IrArgs g) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
+  constexpr int ROWS = BMt + BNt;
+  constexpr int ROWB = 64;               // 32 channels per staged row
+  constexpr int STAGE = ROWS * ROWB;
+  constexpr int IPW = ROWS / 16 / NW;
+  constexpr int EROW = 64 * 4 + 16;
+  constexpr int EP = (NW * 64 * EROW <= NST * STAGE) ? 1 : 2;
+  static_assert(ROWS % (16 * NW) == 0 && NST >= 3 && NST <= 4, "tile");
+  static_assert(NW * (64 / EP) * EROW <= NST * STAGE, "epilogue staging fits the ring");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int wm = wave % WGM, wn = wave / WGM;
+  const int ntile = g.tiles_m * g.tiles_n;
+  int tile;
+  {
+    const int id = blockIdx.x, xcd = id & 7, q = ntile >> 3, r = ntile & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BMt, n0 = tn * BNt;
+  const int RS = g.R * g.R;
+
+  const uint16_t *zp = reinterpret_cast<const uint16_t *>(&g_tn_zero);
+  const uint16_t *base[IPW];
+  uint32_t vmask[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int u = wave * IPW + i;
+    const int rr = 16 * u + (lane >> 2);
+    const int c = (lane & 3) ^ ((rr >> 2) & 3);
+    if (u < BMt / 16) {      // pixel rows (wave-uniform: a unit never straddles the two operands)
+      const int m = m0 + rr;
+      const int ohow = g.OH * g.OW;
+      const int mm = m < g.M ? m : g.M - 1;
+      const int n = mm / ohow;
+      const int rem = mm - n * ohow;
+      const int oh = rem / g.OW, ow = rem - oh * g.OW;
+      const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+      uint32_t vm = 0;
+      if (m < g.M)
+        for (int t = 0; t < RS; ++t) {
+          const int ih = ih0 + t / g.R, iw = iw0 + t % g.R;
+          if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) vm |= 1u << t;
+        }
+      vmask[i] = vm;
+      base[i] = g.x + (((long long)n * g.H + ih0) * g.W + iw0) * g.Cin + c * 8;   // dereferenced only where vmask allows
+    } else {
+      const int k = n0 + rr - BMt;
+      vmask[i] = k < g.Kout ? 0x1ffu : 0u;
+      base[i] = g.wp + (long long)(k < g.Kout ? k : 0) * RS * g.Cin + c * 8;
+    }
+  }
+  // the stage the NEXT issue() fetches: tap (ir, is), channel offset ic0 — advanced once per call
+  int ir = 0, is = 0, ic0 = 0;
+  auto issue = [&](int buf) {
+    const int tap = ir * g.R + is;
+    const long long off_x = ((long long)ir * g.W + is) * g.Cin + ic0;
+    const long long off_w = (long long)tap * g.Cin + ic0;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int u = wave * IPW + i;
+      lds_ptr_t d = (lds_ptr_t)(lds + buf * STAGE + u * 1024);
+      const uint16_t *q = base[i] + (u < BMt / 16 ? off_x : off_w);
+      const uint16_t *p = ((vmask[i] >> tap) & 1u) ? q : zp;
+      __builtin_amdgcn_global_load_lds(p, d, 16, 0, 0);
+    }
+    ic0 += 32;
+    if (ic0 == g.Cin) {
+      ic0 = 0;
+      if (++is == g.R) { is = 0; ++ir; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+  const int sw = (lo >> 2) & 3;
+  const int x_row = (wm * 64 + lo) * ROWB;
+  const int w_row = (BMt + wn * 64 + lo) * ROWB;
+  const int ch0 = ((0 + hi) ^ sw) * 16, ch1 = ((2 + hi) ^ sw) * 16;
+
+  auto compute = [&](int buf) {
+    const char *bs = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = kk ? ch1 : ch0;
+      const g_bf16x8 w0 = *reinterpret_cast<const g_bf16x8 *>(bs + w_row + ch);
+      const g_bf16x8 w1 = *reinterpret_cast<const g_bf16x8 *>(bs + w_row + 32 * ROWB + ch);
+      const g_bf16x8 x0 = *reinterpret_cast<const g_bf16x8 *>(bs + x_row + ch);
+      const g_bf16x8 x1 = *reinterpret_cast<const g_bf16x8 *>(bs + x_row + 32 * ROWB + ch);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[1][1], 0, 0, 0);
+    }
+  };
+
+  const int nk = RS * (g.Cin >> 5);
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nk) issue(s0);
+  int buf = 0, nbuf = NST - 1;
+  for (int f = 0; f < nk; ++f) {
+    const int later = nk - 1 - f;
+    if (later >= NST - 2) GB_WAIT_VM(IPW * (NST - 2));
+    else if (NST == 4 && later == 1) GB_WAIT_VM(IPW);
+    else GB_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    if (f + NST - 1 < nk) issue(nbuf);
+    compute(buf);
+    buf = (buf + 1 == NST) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
+  }
+
+  // ---- epilogue through LDS (as k_gemm_bf16_nt_r), plus the per-image channel offset
+  __builtin_amdgcn_s_barrier();
+  char *er = lds + wave * ((64 / EP) * EROW);
+  const int fr = (lane & 7) * 8;
+  const int kcol = n0 + wn * 64 + fr;
+  float bsv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsv[e] = 0.f;
+  if (g.bias) {
+    const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + kcol);
+    const float4 b1 = *reinterpret_cast<const float4 *>(g.bias + kcol + 4);
+    bsv[0] = b0.x; bsv[1] = b0.y; bsv[2] = b0.z; bsv[3] = b0.w; bsv[4] = b1.x; bsv[5] = b1.y; bsv[6] = b1.z; bsv[7] = b1.w;
+  }
+  const int ohow = g.OH * g.OW;
+#pragma unroll
+  for (int pass = 0; pass < EP; ++pass) {
+#pragma unroll
+    for (int bb = 0; bb < 2 / EP; ++bb) {
+      const int b = (EP == 2) ? pass : bb;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v4 = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+          *reinterpret_cast<float4 *>(er + (bb * 32 + lo) * EROW + (a * 32 + 8 * q + 4 * hi) * 4) = v4;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int i = 0; i < 8 / EP; ++i) {
+      const int trow = i * 8 + (lane >> 3);
+      const int m = m0 + wm * 64 + pass * 32 + trow;
+      const float4 u0 = *reinterpret_cast<const float4 *>(er + trow * EROW + fr * 4);
+      const float4 u1 = *reinterpret_cast<const float4 *>(er + trow * EROW + fr * 4 + 16);
+      if (m < g.M) {
+        float o[8] = {u0.x + bsv[0], u0.y + bsv[1], u0.z + bsv[2], u0.w + bsv[3],
+                      u1.x + bsv[4], u1.y + bsv[5], u1.z + bsv[6], u1.w + bsv[7]};
+        if (g.nbias) {
+          const float *nb = g.nbias + (size_t)(m / ohow) * g.Kout + kcol;
+          const float4 n0v = *reinterpret_cast<const float4 *>(nb);
+          const float4 n1v = *reinterpret_cast<const float4 *>(nb + 4);
+          o[0] += n0v.x; o[1] += n0v.y; o[2] += n0v.z; o[3] += n0v.w; o[4] += n1v.x; o[5] += n1v.y; o[6] += n1v.z; o[7] += n1v.w;
+        }
+        const size_t e = (size_t)m * g.Kout + kcol;
+        if (g.addend) {
+          const uint4 av = *reinterpret_cast<const uint4 *>(g.addend + e);
+          o[0] += gb_lo(av.x); o[1] += gb_hi(av.x); o[2] += gb_lo(av.y); o[3] += gb_hi(av.y);
+          o[4] += gb_lo(av.z); o[5] += gb_hi(av.z); o[6] += gb_lo(av.w); o[7] += gb_hi(av.w);
+        }
+        *reinterpret_cast<uint4 *>(g.y + e) = make_uint4(gb_pack2(o[0], o[1]), gb_pack2(o[2], o[3]), gb_pack2(o[4], o[5]),
+                                                         gb_pack2(o[6], o[7]));
+      }
+    }
+    if (EP == 2 && pass == 0) __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+
+template <int WGM, int WGN, int NST>
+int launch_conv_ring(const IrArgs &g0, hipStream_t st) {
+  IrArgs g = g0;
+  constexpr int BMt = 64 * WGM, BNt = 64 * WGN;
+  g.tiles_m = (g.M + BMt - 1) / BMt;
+  g.tiles_n = g.Kout / BNt;
+  const size_t ldsb = (size_t)NST * (BMt + BNt) * 64;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_bf16_ring<WGM, WGN, NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_conv_bf16_ring<WGM, WGN, NST>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ K16 TN (weight gradients)
 // dW[Na][Nb] (fp32) (+)= sum_m dY[m][Na] . X[m][Nb]: the reduction index is the SLOW axis of both operands, so the 16-byte
 // pieces the DMA drops into LDS hold 8 features of ONE token and an MFMA operand (8 tokens of one feature) is gathered by
@@ -1011,7 +1233,6 @@ int launch_gemm_bf16_r(const GbArgs &g0, hipStream_t st) {
 // several write fp32 partials that k_tn_reduce folds in index order (deterministic, no atomics).
 typedef short g_s16x4 __attribute__((ext_vector_type(4)));
 typedef g_s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr_t;
-__device__ uint4 g_tn_zero = {0u, 0u, 0u, 0u};
 
 struct TnArgs {
   const uint16_t *dy;  // [M][Na] bf16
@@ -1326,6 +1547,33 @@ int launch_gemm_bf16_p(const GbArgs &g0, hipStream_t st) {
 }
 
 }  // namespace
+
+// Internal (not exported): salun_conv2d_bf16_forward (salun_conv_bf16.hip) tries this first.  Returns 1 when the ring
+// kernel took the convolution, 0 when the shape is left to the register-staged kernel (few tiles: that one can split the
+// reduction; channel counts that do not tile), a negative error otherwise.
+extern "C" int salun_conv2d_bf16_forward_ring(const uint16_t *x, const uint16_t *wp, const float *bias, const float *nbias,
+                                              const uint16_t *addend, uint16_t *y, int N, int H, int W, int C, int K, int R,
+                                              int stride, int pad, hipStream_t st) {
+  static const int on = [] { const char *e = getenv("SALUN_CONV_RING"); return e ? atoi(e) : 1; }();
+  const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
+  const int64_t M = (int64_t)N * OH * OW;
+  if (!on || C % 32 != 0 || K % 64 != 0 || (R != 1 && R != 3) || M >= (1 << 30)) return 0;
+  // Measured on the SD layer table (tools/convbench_bf16.py, round 4): the ring wins the 1 x 1 convolutions (299 vs 229 and
+  // 282 vs 188 TFLOP/s) and LOSES the 3 x 3 ones (442 vs 540 TFLOP/s over the table: 90 .. 720 stages of 8 MFMAs per wave,
+  // gathered 64-byte rows through the LDS-DMA path, which the register-staged kernel with its 128 x 256 tiles out-runs).
+  // on == 3 forces it for every eligible shape (tests, A/B).
+  if (R != 1 && on != 3 && on != 2) return 0;
+  if ((bias && !salun_aligned16(bias)) || (nbias && !salun_aligned16(nbias)) || (addend && !salun_aligned16(addend)) ||
+      !salun_aligned16(y))
+    return 0;
+  IrArgs g{x, wp, bias, nbias, addend, y, (int)M, H, W, C, OH, OW, K, R, stride, pad, 0, 0};
+  const int64_t t256 = (M + 255) / 256;
+  if (on == 2 && K % 128 == 0) return launch_conv_ring<2, 2, 4>(g, st) == SALUN_OK ? 1 : SALUN_EIO;   // A/B: pin the 128 x 128 form
+  if (K % 128 == 0 && t256 * (K / 128) >= 128) return launch_conv_ring<4, 2, 3>(g, st) == SALUN_OK ? 1 : SALUN_EIO;
+  if (K % 128 != 0 && t256 * (K / 64) >= 128) return launch_conv_ring<4, 1, 3>(g, st) == SALUN_OK ? 1 : SALUN_EIO;
+  if (K % 128 == 0 && ((M + 127) / 128) * (K / 128) >= 128) return launch_conv_ring<2, 2, 4>(g, st) == SALUN_OK ? 1 : SALUN_EIO;
+  return 0;
+}
 
 SALUN_EXPORT int salun_gemm_bf16_supported(int64_t M, int N, int K) {
   return (M >= 1 && N >= 64 && K >= 64 && N % 64 == 0 && K % 64 == 0 && M * (int64_t)K < (1ll << 31) &&

@@ -25,6 +25,8 @@ import ctypes
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+
+from .fastfn import FastFunction
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -148,7 +150,7 @@ def _eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
             and 2.0 * x.numel() * weight.shape[0] <= LINEAR_MAX_FLOP)
 
 
-class _Linear(torch.autograd.Function):
+class _Linear(FastFunction):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x2 = x.reshape(-1, x.shape[-1])
@@ -214,7 +216,7 @@ def use_salun_linears(model: nn.Module, skip: Sequence[str] = ()) -> int:
 
 
 # ------------------------------------------------------------------------ grouped Linear (shared input)
-class _GroupedLinear(torch.autograd.Function):
+class _GroupedLinear(FastFunction):
     """y_g = x W_g^T + b_g for g = 0..G-1 with ONE input x [M, K]."""
 
     @staticmethod
@@ -322,7 +324,7 @@ def _dense_like(t: torch.Tensor) -> torch.Tensor:
     return torch.empty(t.shape, dtype=t.dtype, device=t.device)
 
 
-class _AttentionF32(torch.autograd.Function):
+class _AttentionF32(FastFunction):
     """q [B, H, Tq, D], k / v [B, H, Tk, D] (views of any strides with one unit-stride dimension among the last two)."""
 
     @staticmethod

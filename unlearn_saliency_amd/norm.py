@@ -9,13 +9,15 @@ the library's BN kernels, a ReLU, an add, a ReLU-backward and a gradient add —
 from __future__ import annotations
 
 import torch
+
+from .fastfn import FastFunction
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import gradsink, ops
 
 
-class _FusedBN(torch.autograd.Function):
+class _FusedBN(FastFunction):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, nbt=None):
         out = ops.bn_forward(x, residual, weight, bias, running_mean, running_var, training, momentum, eps, relu, nbt)
@@ -62,7 +64,7 @@ def fused_bn_act(x: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor = N
                           bn.momentum, bn.eps, relu, bn.num_batches_tracked)  # the kernel bumps the counter
 
 
-class _FusedGN(torch.autograd.Function):
+class _FusedGN(FastFunction):
     @staticmethod
     def forward(ctx, x, weight, bias, groups, eps, silu):
         out = ops.gn_forward(x, weight, bias, groups, eps, silu)
@@ -87,7 +89,7 @@ class _FusedGN(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None
 
 
-class _FusedGN16(torch.autograd.Function):
+class _FusedGN16(FastFunction):
     """GroupNorm (+ SiLU) of a bf16 activation on csrc/salun_norm_bf16.hip (K12): NHWC bf16 in / out, fp32 statistics.
     The input may be any 4-D bf16 device tensor (logical NCHW); `channels_last` inputs are used as they are."""
 

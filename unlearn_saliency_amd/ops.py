@@ -11,12 +11,16 @@ from typing import Optional, Sequence
 
 import torch
 
+from .fastfn import FastFunction
+
 from . import _lib
 from ._lib import c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p, check
 
 
 def _stream() -> c_void_p:
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of the current device's current stream (what torch.cuda.current_stream().cuda_stream returns, without
+    # building a Stream object and re-probing the device on each of ~4,500 calls per SD step)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _dev(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, allow_none: bool = False) -> c_void_p:
@@ -45,7 +49,7 @@ def workspace(nbytes: int, device: torch.device, tag: str = "") -> torch.Tensor:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     # the top-k publication block is keyed by the device alone: mask_topk_status / mask_topk_thresholds must find the
     # block the last mask_topk call wrote whatever stream is current when they are called (side streams exist)
-    key = (idx, None if tag == "topk" else torch.cuda.current_stream(idx).cuda_stream, tag)
+    key = (idx, None if tag == "topk" else torch._C._cuda_getCurrentRawStream(idx), tag)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -251,7 +255,7 @@ def sqerr_loss(a: torch.Tensor, b: torch.Tensor, coef: float, want_per_sample: b
     return loss, per, d
 
 
-class _SqErr(torch.autograd.Function):
+class _SqErr(FastFunction):
     """coef * sum((target - pred)^2) with the gradient produced in the same pass."""
 
     @staticmethod
@@ -289,7 +293,7 @@ def dropout(x: torch.Tensor, p: float, key: int, sample_offset: int = 0, out: Op
     return y
 
 
-class _Dropout(torch.autograd.Function):
+class _Dropout(FastFunction):
     @staticmethod
     def forward(ctx, x, p, key, offset):
         ctx.cfg = (float(p), int(key), int(offset))
@@ -618,7 +622,7 @@ def attn_backward(q, k, v, o, d_o, lse, scale: float):
     return dq, dk, dv
 
 
-class _Attn(torch.autograd.Function):
+class _Attn(FastFunction):
     @staticmethod
     def forward(ctx, q, k, v, scale):
         o, lse = attn_forward(q, k, v, scale, need_lse=True)
@@ -641,7 +645,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -
 
 
 # ----------------------------------------------------------------------------- K14
-class _LayerNorm16(torch.autograd.Function):
+class _LayerNorm16(FastFunction):
     """LayerNorm over the last dimension of a bf16 token tensor (csrc/salun_tok_bf16.hip): bf16 in / out, fp32 stats."""
 
     @staticmethod
@@ -685,7 +689,7 @@ def layer_norm_bf16(x: torch.Tensor, ln: "torch.nn.LayerNorm") -> torch.Tensor:
     return _LayerNorm16.apply(x, ln.weight, ln.bias, float(ln.eps))
 
 
-class _Geglu16(torch.autograd.Function):
+class _Geglu16(FastFunction):
     """out = h[..., :F] * gelu(h[..., F:]) on a bf16 tensor (csrc/salun_tok_bf16.hip)."""
 
     @staticmethod

@@ -16,6 +16,8 @@ then runs its ordinary forward.
 from __future__ import annotations
 
 import torch
+
+from .fastfn import FastFunction
 import torch.nn as nn
 
 import os
@@ -117,7 +119,7 @@ def _bn_args(bn: nn.BatchNorm2d):
     return bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps
 
 
-class _BasicBlockFn(torch.autograd.Function):
+class _BasicBlockFn(FastFunction):
     @staticmethod
     def forward(ctx, x, blk, w1, g1, b1, w2, g2, b2, wd, gd, bd):
         s = blk.conv1.stride[0]
@@ -278,7 +280,7 @@ def fused_basic_block(blk, x: torch.Tensor):
 # gradient, and folded over the batch conv1's bias gradient — and norm1's backward adds the skip branch's gradient
 # before its store; conv2's and the skip convolution's bias gradients share one streaming channel sum of dout; weight
 # gradients go to the side stream and straight into `.grad` (gradsink), as for the BasicBlock above.
-class _DiffusionResnetBlockFn(torch.autograd.Function):
+class _DiffusionResnetBlockFn(FastFunction):
     @staticmethod
     def forward(ctx, x, proj, blk, n1w, n1b, w1, b1, n2w, n2b, w2, b2, ws, bs):
         N, C, H, W = x.shape

@@ -7,9 +7,13 @@ the arguments) and probes `setup_context` before it reaches the C++ `apply`; und
 import torch
 
 
+_transforms_active = getattr(torch._C, "_are_functorch_transforms_active", None)
+
+
 class FastFunction(torch.autograd.Function):
-    @classmethod
-    def apply(cls, *args):
-        if torch._C._are_functorch_transforms_active():
-            return super().apply(*args)
-        return super(torch.autograd.Function, cls).apply(*args)
+    if _transforms_active is not None:  # (a torch without the probe keeps the stock `apply`)
+        @classmethod
+        def apply(cls, *args):
+            if _transforms_active():
+                return super().apply(*args)
+            return super(torch.autograd.Function, cls).apply(*args)

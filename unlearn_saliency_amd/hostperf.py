@@ -10,5 +10,8 @@ import gc
 
 
 def freeze_gc() -> None:
+    # unfreeze first: what an earlier call froze and has since become garbage (a previous run's model in the same process)
+    # goes back to the collector instead of staying immortal
+    gc.unfreeze()
     gc.collect()
     gc.freeze()

@@ -17,10 +17,21 @@ from . import _lib
 from ._lib import c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p, check
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _stream_handle(idx: Optional[int] = None) -> int:
+    """The raw handle of device `idx`'s (default: the current device's) current stream — what
+    `torch.cuda.current_stream(idx).cuda_stream` returns, without building a Stream object and re-probing the device on
+    each of ~4,500 calls per SD step."""
+    if _raw_stream is None or _cur_device is None:
+        return torch.cuda.current_stream(idx).cuda_stream
+    return _raw_stream(_cur_device() if idx is None else idx)
+
+
 def _stream() -> c_void_p:
-    # the raw handle of the current device's current stream (what torch.cuda.current_stream().cuda_stream returns, without
-    # building a Stream object and re-probing the device on each of ~4,500 calls per SD step)
-    return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    return c_void_p(_stream_handle())
 
 
 def _dev(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, allow_none: bool = False) -> c_void_p:
@@ -49,7 +60,7 @@ def workspace(nbytes: int, device: torch.device, tag: str = "") -> torch.Tensor:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     # the top-k publication block is keyed by the device alone: mask_topk_status / mask_topk_thresholds must find the
     # block the last mask_topk call wrote whatever stream is current when they are called (side streams exist)
-    key = (idx, None if tag == "topk" else torch._C._cuda_getCurrentRawStream(idx), tag)
+    key = (idx, None if tag == "topk" else _stream_handle(idx), tag)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -29,7 +29,7 @@ class _ScaleStock(torch.autograd.Function):
 def test_fast_function_matches_the_stock_apply_including_none_and_non_tensor_arguments():
     x = torch.randn(5, 3, dtype=torch.float64, requires_grad=True)
     e = torch.randn(5, 3, dtype=torch.float64, requires_grad=True)
-    for args in ((x, 3.0), (x, -2.0, None), (x, 0.5, e)):
+    for args in ((x, 3.0, None), (x, -2.0, None), (x, 0.5, e)):
         outs = []
         for fn in (_Scale, _ScaleStock):
             for t in (x, e):

@@ -113,6 +113,9 @@ class LatentDiffusionLite(nn.Module):
 
     def apply_model(self, x_noisy, t, cond):
         if self.bf16:
+            # the 32 to_k / to_v projections each round the text context to bf16 before they read it: do it once (same values)
+            if torch.is_tensor(cond) and cond.dtype == torch.float32 and not cond.requires_grad:
+                cond = cond.to(torch.bfloat16)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return self.model.diffusion_model(x_noisy, t, context=cond).float()
         return self.model.diffusion_model(x_noisy, t, context=cond)

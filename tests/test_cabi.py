@@ -98,3 +98,28 @@ def test_data_workspace_query_is_host_only_and_announces_the_reduction_split(bui
     assert q(256, 64, 32, 32, 3, 1) == 0 and q(256, 512, 4, 4, 3, 1) == 0   # every ResNet-18 layer at batch 256
     assert q(4, 64, 6, 6, 3, 1) == 0                                 # width not a power of two: outside the tiling
     assert q(0, 64, 4, 4, 3, 1) == 0 and q(4, 64, 4, 4, 5, 1) == 0 and q(4, 64, 4, 4, 3, 3) == 0
+
+
+def test_k16_domain_and_workspace_queries_are_host_only(built_lib):
+    """`salun_gemm_bf16_supported`, `salun_gemm_bf16_tn_supported`, `salun_gemm_bf16_tn_workspace_bytes` and the 1x1 route of
+    `salun_conv2d_bf16_wgrad_workspace_bytes` are host arithmetic (no device call): the domains the headers state, and a
+    reduction split that writes whole fp32 images of the weight gradient."""
+    from ctypes import c_int64
+    from unlearn_saliency_amd import _lib
+    L = _lib.lib()
+    nt, tn, tnws = L.salun_gemm_bf16_supported, L.salun_gemm_bf16_tn_supported, L.salun_gemm_bf16_tn_workspace_bytes
+    assert nt(c_int64(32768), 320, 320) and nt(c_int64(1), 64, 64)
+    assert not nt(c_int64(128), 96, 64) and not nt(c_int64(128), 64, 40) and not nt(c_int64(0), 64, 64)
+    assert tn(c_int64(616), 320, 768) and tn(c_int64(1), 32, 32)
+    assert not tn(c_int64(616), 40, 64) and not tn(c_int64(616), 64, 100) and not tn(c_int64(1 << 24), 64, 64)
+    for M, Na, Nb in ((32768, 320, 320), (2048, 1280, 1280), (512, 1280, 5120), (64, 32, 32)):
+        b = tnws(c_int64(M), Na, Nb, 0)
+        assert b % (Na * Nb * 4) == 0                      # 0 (one split adds into dw itself) or `splits` fp32 images
+        assert b // (Na * Nb * 4) <= max(1, M // 256)      # a split reduces over >= 256 tokens
+    assert tnws(c_int64(64), 32, 32, 0) == 0 and tnws(c_int64(32768), 320, 320, 0) > 0
+    assert tnws(c_int64(616), 40, 64, 0) == 0              # outside the domain
+    # a 1x1 / stride-1 / unpadded weight gradient with >= 1024 pixels is the TN GEMM: its partials + the column-sum slab
+    w = L.salun_conv2d_bf16_wgrad_workspace_bytes
+    gemm = tnws(c_int64(8 * 64 * 64), 320, 320, 0)
+    assert w(8, 64, 64, 320, 320, 1, 1, 0) >= gemm > 0
+    assert w(8, 64, 64, 320, 320, 3, 1, 1) > 0 and w(8, 64, 64, 4, 320, 3, 1, 1) == 0

@@ -85,14 +85,21 @@ def parse():
                          "(random / class-wise) forget set partition every global batch; no device work")
     ap.add_argument("--batch_size", type=int, default=256, help="per-GPU batch (reference: 256)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_steps", type=int, default=6,
-                    help="reference-sequence steps timed on the host CPU, in --cpu_repeats groups (SURVEY.md D3 asks 20: "
-                         "capped so the default run stays within minutes; the spread over the groups is reported)")
-    ap.add_argument("--cpu_repeats", type=int, default=3)
+    ap.add_argument("--cpu_steps", type=int, default=12,
+                    help="reference-sequence steps timed on the host CPU, in --cpu_repeats groups (SURVEY.md D3 asks 20 = "
+                         "--cpu_survey: 12 keep the default run, which also carries the DDPM block and its one CPU "
+                         "step, near three minutes; the spread over the groups is reported)")
+    ap.add_argument("--cpu_repeats", type=int, default=4)
     ap.add_argument("--cpu_survey", action="store_true",
                     help="the CPU baseline at the sample sizes SURVEY.md D3 asks for: 20 RL steps (4 groups of 5, ~2 min "
-                         "on 128 threads) instead of the default 6")
+                         "on 128 threads) instead of the default 12")
     ap.add_argument("--no_mask_gen", action="store_true", help="skip timing Phase A (a random mask is used)")
+    ap.add_argument("--no_ddpm", action="store_true",
+                    help="skip the CFG-DDPM class-forget block the default one-GPU line carries beside the ResNet-18 "
+                         "figures (north_star's second target; `--workload ddpm` is the full-length form)")
+    ap.add_argument("--ddpm_steps", type=int, default=10)
+    ap.add_argument("--ddpm_mask_batches", type=int, default=8,
+                    help="forget batches of the embedded DDPM Phase A (the reference's 40 scale linearly)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="1 = keep cudnn.deterministic=True as the reference's setup_seed sets it (restricts MIOpen's "
                          "algorithm choice); 0 = let MIOpen pick its fastest fp32 kernels (same math, fp32)")
@@ -158,7 +165,11 @@ def time_mask_gen(model, forget_loader, criterion):
     (u8 masks resident in HBM).  File writing (10 x 89 MB int64 .pt) is reported separately by generate_mask.py."""
     from unlearn_saliency_amd.Classification.generate_mask import (THRESHOLD_LIST, accumulate_saliency,
                                                                   masks_from_saliency)
-    for _ in range(2):  # first pass warms MIOpen's find-db
+    from unlearn_saliency_amd import ops
+    masks = None
+    for _ in range(2):  # first pass warms the shape-specialised state
+        masks = None  # the ten 11 MB outputs go back to the caching allocator: the timed pass reuses them, as a second
+        #               generate_mask call in one process would
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         acc = accumulate_saliency(forget_loader, model, criterion)
@@ -167,7 +178,41 @@ def time_mask_gen(model, forget_loader, criterion):
         masks = masks_from_saliency(acc, THRESHOLD_LIST)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-    return masks[0.5], {"total_sec": t2 - t0, "saliency_sec": t1 - t0, "topk_10_thresholds_sec": t2 - t1}
+    route, err = ops.mask_topk_status(acc.device)  # 1 = the single-read route served all ten ratios, 2 = full scan
+    # device time of the ten-ratio select alone (HIP events, no host synchronisation or allocation inside): the
+    # reference's own list 0.1 ... 1.0 on THIS accumulator (exact zeros included), output buffers reused
+    n = acc.numel()
+    ks = [int(n * r) for r in THRESHOLD_LIST]
+    outs = [masks[r] for r in THRESHOLD_LIST]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b in ev:
+        a.record()
+        ops.mask_topk(acc, ks, outs)
+        b.record()
+    torch.cuda.synchronize()
+    dev_us = sorted(1e3 * a.elapsed_time(b) for a, b in ev)
+    zeros = int((acc == 0).sum().item())
+    return masks[0.5], {"total_sec": t2 - t0, "saliency_sec": t1 - t0, "topk_10_thresholds_sec": t2 - t1,
+                        "topk_route": route, "topk_error": err,
+                        "topk_10_thresholds_device_us": dev_us[len(dev_us) // 2],
+                        "topk_algorithmic_bytes": 14 * n,
+                        "topk_frac_of_hbm_peak": 14 * n / (dev_us[len(dev_us) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "accumulator_exact_zeros": zeros,
+                        "topk_note": "wall = host call incl. workspace / output allocation and one status read-back; "
+                                     "device = HIP events around salun_mask_topk_ex alone (median of 5), 4 B read + "
+                                     "10 x 1 B written per element"}
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 def cpu_baseline(per_gpu_bs, steps, repeats=3):
@@ -225,8 +270,9 @@ def cpu_baseline(per_gpu_bs, steps, repeats=3):
                                 "ratios at N = 11,173,962, both measured; ratio 0.5 at N_D = 38,632,323",
             "sample": f"{done} RL steps at batch {per_gpu_bs} in {repeats} groups of {per} (ResNet-18 fp32, reference "
                       f"op sequence: fwd+bwd, 62x mask-mul, torch.optim.SGD, 62x restore) after 1 warm-up step; "
-                      f"SURVEY.md D3 asks 20 steps: capped to keep the default run within minutes",
-            "ms_per_step": 1e3 * dt / done, "host_cpu_count": os.cpu_count(),
+                      f"SURVEY.md D3 asks 20 steps (--cpu_survey): capped to keep the default run within minutes",
+            "ms_per_step": 1e3 * dt / done, "host_cpu_count": os.cpu_count(), "cpu_model": cpu_model_name(),
+            "torch_version": torch.__version__,
             "breakdown_ms": {k: 1e3 * v / done for k, v in timers.items()}}
 
 
@@ -457,6 +503,23 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
         samples = float(t.item())
 
+    # calibration, OUTSIDE the timed region (one rank, no collectives): what a HIP-event pair reads with nothing
+    # between the two records, and the same update kernel launched back to back on the same vectors — the account of
+    # how much of the in-step figure is the kernel and how much the two markers around it
+    ev_overhead_us = iso_us = None
+    if world == 1 and not sdist.collectives_on():
+        cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+        for s_, e_ in cal[:20]:
+            s_.record()
+            e_.record()
+        for s_, e_ in cal[20:]:
+            s_.record()
+            opt.step()
+            e_.record()
+        torch.cuda.synchronize()
+        ev_overhead_us = 1e3 * sorted(s_.elapsed_time(e_) for s_, e_ in cal[:20])[10]
+        iso_us = 1e3 * sorted(s_.elapsed_time(e_) for s_, e_ in cal[20:])[10]
+
     # the optimizer tail on the launch stream: at N=1 exactly one kernel (salun_masked_sgd_step)
     tail_ms = sorted(s.elapsed_time(e) for s, e in events)
     tail_mean_s = 1e-3 * sum(tail_ms) / len(tail_ms)
@@ -468,7 +531,7 @@ def main():
     fb_mean_s = 1e-3 * sum(fb_ms) / max(len(fb_ms), 1)
     pmc_traffic, pmc_src = None, None
     try:  # HBM bytes per launch: a CONSTANT read from the committed PMC passes, not measured in this run
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             pth = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if os.path.exists(pth):
                 with open(pth) as f:
@@ -523,7 +586,15 @@ def main():
                          "traffic_source": pmc_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": tail_mean_s * 1e6,
                          "median_launch_us": 1e3 * tail_ms[len(tail_ms) // 2],
-                         "timing": "HIP events on the launch stream around the launch, inside the timed steps"},
+                         "event_pair_overhead_us": ev_overhead_us, "back_to_back_launch_us": iso_us,
+                         "frac_net_of_event_overhead": (None if ev_overhead_us is None else
+                                                        alg_bytes / max(tail_mean_s - 1e-6 * ev_overhead_us, 1e-9) / 1e9
+                                                        / HBM_PEAK_GBS),
+                         "timing": "HIP events on the launch stream around the launch, inside the timed steps (the "
+                                   "first event is recorded after backward's side-stream join, so the pair holds the "
+                                   "kernel and the two markers); `event_pair_overhead_us` = an empty pair, "
+                                   "`back_to_back_launch_us` = the same launch repeated with warm caches, both taken "
+                                   "after the timed region"},
             "fwd_bwd": {"bound": "mfma", "gflop_per_step": flop_per_step_rank,
                         "achieved": flop_per_step_rank / (fb_mean_s * 1e3) if fb_mean_s else None,
                         "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
@@ -539,6 +610,24 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             with contextlib.redirect_stdout(sys.stderr):
                 out["cpu_baseline"] = cpu_baseline(a.batch_size, a.cpu_steps, a.cpu_repeats)
+        if (world == 1 and not a.no_ddpm and a.forget == "random" and a.scaling == "weak"
+                and not sdist.collectives_on()):
+            # north_star's second target beside the headline: CFG-DDPM class-forget (BASELINE configs[3]) — the same
+            # step `--workload ddpm` times, a shorter window, one reference step on the CPU (~80 s on 128 threads)
+            del model, opt, arena, forget_loader, retain_loader, stream
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_ddpm
+            argv = ["--gpus", "1", "--steps", str(a.ddpm_steps), "--warmup", "3", "--mask_batches",
+                    str(a.ddpm_mask_batches), "--cpu_steps", "1"] + (["--no_cpu_baseline"] if a.no_cpu_baseline else [])
+            try:
+                with contextlib.redirect_stdout(sys.stderr):
+                    d = bench_ddpm.run(argv)
+                out["ddpm"] = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype",
+                                                 "config", "samples_per_sec", "mask_gen", "roofline", "fwd_bwd",
+                                                 "cpu_baseline") if k in d}
+            except Exception as exc:  # the headline line must not be lost to the second workload
+                out["ddpm"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(out), flush=True)
     sdist.barrier()
     if sdist.is_dist():

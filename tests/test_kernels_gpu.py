@@ -335,6 +335,126 @@ def test_topk_two_level_route_at_scale(ops, oracle_mod):
     print("top-k at N = 2^27+3: " + ", ".join(f"{k_} {v[2]:.3f} ms" for k_, v in res.items()))
 
 
+def _check_route1(ops, oracle_mod, acc, ks, what=""):
+    """Masks bit-exact against the oracle, thresholds = the k-th |acc|, and the call stayed on the single-read route."""
+    d = dev(acc)
+    got = ops.mask_topk(d, ks)
+    assert ops.mask_topk_status(d.device) == (1, 0), (what, ks)
+    taus = ops.mask_topk_thresholds(d.device, len(ks)).cpu().numpy()
+    want = oracle_mod.mask_topk(acc, ks)
+    n = acc.size
+    for k, g, w, t in zip(ks, got, want, taus):
+        g = g.cpu().numpy()
+        assert int(g.sum()) == min(max(int(k), 0), n), (what, k)
+        assert np.array_equal(g, w), (what, k, int((g != w).sum()))
+        if 0 < k <= n:
+            sel = np.abs(acc[w.astype(bool)])
+            kth = np.nan if np.isnan(sel).any() else sel.min()
+            assert (np.isnan(t) and np.isnan(kth)) or t == kth, (what, k, t, kth)
+    return got
+
+
+@pytest.mark.parametrize("n", [8192, 300_001, 3_000_000])
+def test_topk_zero_block_stays_on_the_single_read_route(ops, oracle_mod, n):
+    """A real accumulator holds several per cent of exact zeros (Classification/generate_mask.py:46-80 ranks them like
+    any other value): thresholds inside the zero block are resolved by the tie pass (lowest flat index first), k >= n is
+    all ones without a select — none of them falls back to the full scan."""
+    acc = oracle_mod.fill_normal(n, 31, 0, 1e-3) * (1.0 + oracle_mod.fill_uniform(n, 32, 0.0, 0.5))
+    rs = np.random.RandomState(n % 1000)
+    z = rs.rand(n) < 0.30                       # scattered zeros ...
+    acc[z] = 0.0
+    acc[n // 3: n // 3 + n // 10] = 0.0         # ... and a contiguous block of them
+    acc[5::97] *= np.where(acc[5::97] == 0, -1.0, 1.0)  # some of them -0.0
+    nz = int((acc != 0).sum())
+    assert 0.5 * n < nz < 0.7 * n
+    for k in (nz - 1, nz, nz + 1, nz + 2, (nz + n) // 2, n - 2, n - 1, n, n + 7):
+        _check_route1(ops, oracle_mod, acc, [k], f"n={n}")
+    # one call: ordinary thresholds, two different zero budgets, everything, nothing
+    _check_route1(ops, oracle_mod, acc, [n // 10, n // 2, nz + 5, n - 100, n, 0, n // 4, nz - 3], f"n={n} mixed")
+
+
+@pytest.mark.parametrize("n", [3_000_000, N18])
+def test_topk_local_concentration_spills_instead_of_falling_back(ops, oracle_mod, n):
+    """A real accumulator is not i.i.d. along the flat index: a layer whose magnitudes sit right at a threshold gives the
+    workgroups that stream it many times the average share of candidates (on the bench's ResNet-18 accumulator two
+    workgroups exceeded a 1.5x slab at ratios 0.8 / 0.9 and sent all ten ratios to the full scan).  What a slab cannot
+    take goes to the threshold's spill row: still the single-read route, still bit-exact."""
+    acc = oracle_mod.fill_normal(n, 51, 0, 1e-3) * (1.0 + oracle_mod.fill_uniform(n, 52, 0.0, 0.5))
+    med = float(np.median(np.abs(acc)))
+    blk = slice(n // 3, n // 3 + 40_000)                     # ~10 chunks whose every element is a candidate at ratio 0.5
+    acc[blk] = med * (1.0 + 1e-4 * oracle_mod.fill_normal(40_000, 53))
+    q8 = float(np.quantile(np.abs(acc), 0.2))                # ... and a block sitting at ratio 0.8
+    blk2 = slice(2 * n // 3, 2 * n // 3 + 30_000)
+    acc[blk2] = q8 * (1.0 + 1e-4 * oracle_mod.fill_normal(30_000, 54))
+    _check_route1(ops, oracle_mod, acc, [n // 2], f"n={n} one ratio")
+    if n <= 3_000_000:
+        _check_route1(ops, oracle_mod, acc, [int(n * r / 10) for r in range(1, 11)], f"n={n} ten ratios")
+    else:
+        _check_route1(ops, oracle_mod, acc, [int(n * 0.8)], f"n={n} ratio 0.8")
+
+
+def test_topk_zero_block_with_nans_falls_back_only_when_the_rank_reaches_them(ops, oracle_mod):
+    n = 200_000
+    acc = oracle_mod.fill_normal(n, 41, 0, 1e-3) * (1.0 + oracle_mod.fill_uniform(n, 42, 0.0, 0.5))
+    acc[10_000:60_000] = 0.0
+    acc[[3, 77_777, 150_000]] = np.nan
+    nz = int(np.count_nonzero(acc[~np.isnan(acc)]))
+    _check_route1(ops, oracle_mod, acc, [nz + 1000, n - 3, n])      # zeros only / every number / everything
+    for k in (n - 2, n - 1):                                        # the k-th largest is a NaN: full scan, same rule
+        d = dev(acc)
+        got = ops.mask_topk(d, [k])[0].cpu().numpy()
+        assert ops.mask_topk_status(d.device) == (2, 0)
+        assert np.array_equal(got, oracle_mod.mask_topk(acc, [k])[0])
+
+
+def test_topk_reference_ratio_list_on_the_bench_accumulator(ops, oracle_mod):
+    """The accumulator bench.py builds (ResNet-18, Kaiming seed 1, one pass over the 4,500 forget samples) ranked for the
+    reference's ten ratios 0.1 ... 1.0 (Classification/generate_mask.py:49-80) in one call: single-read route, bit-exact
+    against the oracle, every threshold published."""
+    import torch.nn as nn
+    import bench
+    from unlearn_saliency_amd.Classification.generate_mask import THRESHOLD_LIST, accumulate_saliency
+    from unlearn_saliency_amd.conv import use_salun_convs
+    from unlearn_saliency_amd.norm import use_fused_bn
+    device = torch.device("cuda", torch.cuda.current_device())
+    model, forget_loader, _ = bench.build_workload(device, 0, 1, 256)
+    use_salun_convs(model)
+    use_fused_bn(model)
+    acc = accumulate_saliency(forget_loader, model, nn.CrossEntropyLoss())
+    assert acc.numel() == N18
+    a = acc.cpu().numpy()
+    zeros = int((a == 0).sum())
+    print(f"bench accumulator: {zeros} exact zeros of {N18} ({100.0 * zeros / N18:.2f} %)")
+    ks = [int(N18 * r) for r in THRESHOLD_LIST]
+    assert ks[-1] == N18
+    _check_route1(ops, oracle_mod, a, ks, "bench accumulator")
+    # a ratio inside the zero block, if there is one
+    if zeros > 1000:
+        _check_route1(ops, oracle_mod, a, [N18 - zeros // 2, N18 - 1], "bench accumulator, zero block")
+
+
+def test_topk_two_level_route_with_a_zero_block(ops):
+    """2^27 + 5 elements, 60 % exact zeros, ratio 0.5 (the threshold is a zero): the two-level bracket lands on the zero
+    key and the tie pass admits the first k - #nonzero zeros.  Size-independent properties (the oracle would sort 134 M
+    values): popcount, every non-zero selected, the selected zeros are a prefix of the zeros in flat-index order."""
+    n = (1 << 27) + 5
+    d = ops.fill_normal(n, 321, 0.0, 1e-3) * (1.0 + ops.fill_uniform(n, 322, 0.0, 0.5))
+    d[ops.fill_uniform(n, 323, 0.0, 1.0) < 0.6] = 0.0
+    nz = int((d != 0).sum().item())
+    k = int(n * 0.5)
+    assert nz < k
+    m = ops.mask_topk(d, [k])[0]
+    assert ops.mask_topk_status(d.device) == (1, 0)
+    assert ops.mask_popcount(m) == k
+    assert bool(m[d != 0].all())
+    zsel = m[d == 0]
+    assert int(zsel.sum().item()) == k - nz
+    assert bool(zsel[:k - nz].all()) and not bool(zsel[k - nz:].any())
+    assert ops.mask_topk_thresholds(d.device, 1)[0].item() == 0.0
+    full = ops.mask_topk(d, [k], flags=FULL)[0]
+    assert torch.equal(full, m)
+
+
 def test_mask_format_roundtrip(ops, oracle_mod):
     n = 100_003
     m = (oracle_mod.fill_u8(n, 5) & 1).astype(np.uint8)

@@ -86,6 +86,36 @@ def cpu_baseline(cfg, steps=3):
 
 
 def main(argv=None):
+    out = run(argv)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    from unlearn_saliency_amd import dist as sdist
+    sdist.barrier()
+    if sdist.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+def pmc_tail_traffic():
+    """HBM bytes of the optimizer tail (salun_grad_sqnorm + salun_masked_adam_step at N_D) from the committed PMC passes:
+    a CONSTANT (counters cannot be collected inside a timed run), labelled as such."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rnd in ("r05", "r04", "r03", "r02"):
+        pth = os.path.join(root, "profiles", f"{rnd}_pmc_traffic.json")
+        if not os.path.exists(pth):
+            continue
+        try:
+            with open(pth) as f:
+                kern = json.load(f)["kernels"]
+            t = kern[f"k_sqnorm_partial@{rnd}_nd"]["traffic_bytes"] + kern[f"k_masked_adam@{rnd}_nd"]["traffic_bytes"]
+            return t, (f"constant from profiles/{rnd}_pmc_traffic.json (k_sqnorm_partial + k_masked_adam at N_D; rocprofv3 "
+                       f"--pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc.sh) — not measured in this run")
+        except Exception:
+            continue
+    return None, None
+
+
+def run(argv=None):
+    """One DDPM measurement; returns the result dict on rank 0 (None elsewhere).  bench.py's default line embeds it."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -210,7 +240,7 @@ def main(argv=None):
                                       + ("" if not sdist.collectives_on() else " (+ gradient-bucket join)"),
                             "bound": "hbm", "achieved": alg / tail_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                             "frac": alg / tail_s / 1e9 / 8000.0, "mean_tail_us": tail_s * 1e6, "algorithmic_bytes": alg,
-                            "traffic": None},
+                            "traffic": pmc_tail_traffic()[0], "traffic_source": pmc_tail_traffic()[1]},
                "fwd_bwd": {"bound": "mfma", "tflop_per_step": flops_step_rank / 1e12,
                            "achieved_whole_step": flops_step_rank / (dt / a.steps) / 1e12, "peak": 157.3,
                            "frac_whole_step": flops_step_rank / (dt / a.steps) / 1e12 / 157.3, "unit": "TFLOP/s"},
@@ -223,10 +253,8 @@ def main(argv=None):
         if world == 1 and not a.no_cpu_baseline:
             with contextlib.redirect_stdout(sys.stderr):
                 out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_steps)
-        print(json.dumps(out), flush=True)
-    sdist.barrier()
-    if sdist.is_dist():
-        torch.distributed.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

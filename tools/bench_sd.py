@@ -36,9 +36,6 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--library_conv", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the whole unlearning step into a HIP graph (graphs.StepGraph) and replay it: one host "
-                         "call per step instead of ~15,000 launches")
     ap.add_argument("--own_linear", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--library_linear", action="store_true",
                     help="A/B: leave the transformer blocks' Linear layers on the library GEMM (hipBLASLt under autocast) "
@@ -113,52 +110,26 @@ def main(argv=None):
         loss = ops.mse_loss(pseudo_out, forget_out) + 0.1 * remain_loss
         loss.backward()
         run.last_loss = loss.detach()
-        if run.graph is None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            opt.step()
-            e1.record()
-            run.tail.append((e0, e1))
-        else:
-            opt.step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        opt.step()
+        e1.record()
+        run.tail.append((e0, e1))
         return (loss.detach(),)
 
     def run(k):
         model.train()
         run.tail = []
         for (z_f, c_f, c_p), (z_r, c_r) in zip(fdl(k), rdl(k)):
-            if run.graph is not None and run.graph is not False:
-                run.last_loss = run.graph(z_f, c_f, c_p, z_r, c_r)[0]
-            else:
-                one_step(z_f, c_f, c_p, z_r, c_r)
+            one_step(z_f, c_f, c_p, z_r, c_r)
         return run.tail
 
-    run.graph = None
     from unlearn_saliency_amd.optim import FusedMaskedAdam
     run.opt = FusedMaskedAdam(arena, lr=1e-5)
     run.opt.set_mask(m)
     from unlearn_saliency_amd import hostperf
     hostperf.freeze_gc()  # what the training loops of train_scripts.py do before their first step
     run(a.warmup)
-    graph_note = None
-    if a.graph:
-        from unlearn_saliency_amd.graphs import StepGraph
-        run.opt.use_device_step()
-        model.train()
-        (z_f, c_f, c_p), (z_r, c_r) = fdl(1)[0], rdl(1)[0]
-        tg = time.perf_counter()
-        try:
-            def bump():
-                run.opt.steps += 1
-            run.graph = False  # one_step must not record timing events while it is being captured
-            sg = StepGraph(one_step, (z_f, c_f, c_p, z_r, c_r), warmup=2, on_replay=bump)
-            run.graph = sg
-            graph_note = {"captured": True, "capture_sec": time.perf_counter() - tg}
-        except Exception as e:  # noqa: BLE001 - report and fall back to the eager step
-            run.graph = None
-            graph_note = {"captured": False, "error": repr(e)[:400]}
-            print("graph capture failed:", repr(e), file=sys.stderr)
-            torch.cuda.synchronize()
     torch.cuda.synchronize()
     sdist.barrier()
     if os.environ.get("SALUN_SYNC_DEBUG"):  # diagnostics: warn on every host-synchronising call inside the timed steps
@@ -177,14 +148,6 @@ def main(argv=None):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    if not tail:  # graph mode: the optimizer tail is inside the graph; time the same kernels in three eager calls
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            run.opt.step()
-            e1.record()
-            tail.append((e0, e1))
-        torch.cuda.synchronize()
     tail_ms = sum(e0.elapsed_time(e1) for e0, e1 in tail) / len(tail)
     # step = 3 forwards + 2 backwards (2x forward each) + 2 recomputed forwards (activation checkpointing)
     tflop = B * FWD_TFLOP_PER_SAMPLE * (3 + 4 + 2)
@@ -216,7 +179,6 @@ def main(argv=None):
                     "attention": "K13 fused bf16" if a.bf16 else "library scaled_dot_product_attention",
                     "layer_norm_geglu": "K14 bf16 tokens" if a.bf16 else "library"},
         "hbm_peak_alloc_GB": torch.cuda.max_memory_allocated() / 1e9,
-        "hip_graph": graph_note,
     }
     if a.digest:
         import hashlib

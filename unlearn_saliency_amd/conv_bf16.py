@@ -121,6 +121,10 @@ _USE_K16 = [_os.environ.get("SALUN_LINEAR_GEMM", "1") != "0"]
 _K16_VARIANT = [int(_os.environ.get("SALUN_LINEAR_GEMM_VARIANT", "0"))]
 
 
+def _al16(t) -> bool:
+    return t is None or t.data_ptr() % 16 == 0
+
+
 class _LinearBF16Fn(FastFunction):
     """y = x W^T + b (+ addend) on bf16 tokens.  Forward and input gradient: K16 (csrc/salun_gemm.hip, direct-to-LDS
     GEMM on the [N, K] / [K, N] weight images) when the feature counts are multiples of 64, else the K11 1x1
@@ -132,7 +136,9 @@ class _LinearBF16Fn(FastFunction):
         x2 = x.to(torch.bfloat16).contiguous().view(-1, C)
         M = x2.shape[0]
         a2 = addend.to(torch.bfloat16).contiguous().view(-1, K) if addend is not None else None
-        k16 = _USE_K16[0] and ops.gemm_bf16_supported(M, K, C)
+        # K16 reads 16-byte vectors: bias / addend can be views at any 4-byte offset of the flat arena (an odd-sized
+        # parameter ahead of them), in which case the K11 kernels, which take any alignment, serve the layer
+        k16 = (_USE_K16[0] and ops.gemm_bf16_supported(M, K, C) and _al16(x2) and _al16(bias) and _al16(a2))
         if k16:
             y = ops.gemm_bf16_nt(x2, mod.packed_weight().view(K, C), bias, a2, _K16_VARIANT[0])
         else:
@@ -165,7 +171,7 @@ class _LinearBF16Fn(FastFunction):
             if dst is None:
                 dw = got.view(K, C)
         if ctx.needs_input_grad[0]:
-            if _USE_K16[0] and ops.gemm_bf16_supported(M, C, K):
+            if _USE_K16[0] and ops.gemm_bf16_supported(M, C, K) and _al16(dy2):
                 dx = ops.gemm_bf16_nt(dy2, mod.packed_weight_t(), None, None, _K16_VARIANT[0]).view(ctx.x_shape)
             else:
                 dx = ops.conv2d_bf16_backward_data(as_img(dy2, K), mod.packed_weight(), (1,) + tuple(as_img(x2, C).shape[1:]),

@@ -490,21 +490,21 @@ int launch_bwd(const AttnArgs &a, hipStream_t st) {
                      a.do_ld, a.B, a.H, a.Nq, D);
   SALUN_LAUNCH_CHECK();
   const size_t lds_q = 2 * (size_t)KT * G::ROWB + (size_t)G::NT * KT * 64;
-  static bool attr_q = false, attr_kv = false;
-  if (!attr_q) {
+  static unsigned long long attr_q = 0, attr_kv = 0;  // one bit per device
+  if (!((attr_q >> salun_device_bit()) & 1ull)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_dq<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_q) != hipSuccess)
       return SALUN_EIO;
-    attr_q = true;
+    attr_q |= 1ull << salun_device_bit();
   }
   hipLaunchKernelGGL(attn_bwd_dq<D>, dim3((a.Nq + 127) / 128, a.B * a.H), dim3(256), lds_q, st, a);
   SALUN_LAUNCH_CHECK();
   const size_t lds_kv = 2 * (size_t)32 * G::ROWB + 2 * (size_t)G::NT * 32 * 64 + 2 * 32 * sizeof(float);
-  if (!attr_kv) {
+  if (!((attr_kv >> salun_device_bit()) & 1ull)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_dkv<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_kv) != hipSuccess)
       return SALUN_EIO;
-    attr_kv = true;
+    attr_kv |= 1ull << salun_device_bit();
   }
   hipLaunchKernelGGL(attn_bwd_dkv<D>, dim3((a.Nk + 127) / 128, a.B * a.H), dim3(256), lds_kv, st, a);
   SALUN_LAUNCH_CHECK();

@@ -29,6 +29,20 @@ static inline int salun_grid_for(int64_t work_items, int per_block) {
   return static_cast<int>(b);
 }
 
+// Bit index of the calling thread's current device.  hipFuncSetAttribute's dynamic-LDS opt-in is per DEVICE: "done
+// once" flags are kept as one bit per device so a process that drives several GPUs configures each of them.
+static inline int salun_device_bit() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev & 63;
+}
+static inline bool salun_once_per_device(unsigned long long *done) {  // true the first time on this device
+  const int b = salun_device_bit();
+  if ((*done >> b) & 1ull) return false;
+  *done |= 1ull << b;
+  return true;
+}
+
 static inline bool salun_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline bool salun_aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 

@@ -1736,9 +1736,9 @@ struct TileGeom {
 // so it is made once per kernel (process-wide table, the only mutable global state of the library).
 inline void allow_lds_once(const void *fn) {
   static std::mutex mu;
-  static std::unordered_set<const void *> done;
+  static std::unordered_set<uintptr_t> done;  // (kernel, device): the opt-in is per device
   std::lock_guard<std::mutex> lk(mu);
-  if (done.insert(fn).second)
+  if (done.insert(reinterpret_cast<uintptr_t>(fn) ^ ((uintptr_t)(salun_device_bit() + 1) << 56)).second)
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <typename F>

@@ -594,12 +594,12 @@ int launch_igemm(IgArgs a, void *ws, size_t ws_bytes, hipStream_t st) {
   constexpr int A_BYTES = BM * ROWB;
   constexpr int B_BYTES = BTR ? (BN / 32) * (BK * 64) : BN * ROWB;
   const size_t lds = 2 * (size_t)(A_BYTES + B_BYTES);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (!((attr_done >> salun_device_bit()) & 1ull)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_igemm<WM, WN, BK, BTR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SALUN_EIO;
-    attr_done = true;
+    attr_done |= 1ull << salun_device_bit();
   }
   const int mt = (a.M + BM - 1) / BM, nt = (a.Kout + BN - 1) / BN;
   const int nstage = a.R * a.R * (a.Cin / BK);
@@ -637,12 +637,12 @@ template <int R, int ST>
 int launch_wgrad(const WgArgs &a, int splits, hipStream_t st) {
   constexpr int PW = 7 * ST + R;
   const size_t lds = 2 * (size_t)(2 * 64 * 64 + 2 * PW * PW * 64);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device
+  if (!((attr_done >> salun_device_bit()) & 1ull)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_wgrad<R, ST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SALUN_EIO;
-    attr_done = true;
+    attr_done |= 1ull << salun_device_bit();
   }
   dim3 grid((a.K + 63) / 64, (a.C + 63) / 64, splits);
   hipLaunchKernelGGL((conv_bf16_wgrad<R, ST>), grid, dim3(256), lds, st, a);
@@ -747,15 +747,19 @@ static bool tn_route(int64_t M, int C, int K, int R, int stride, int pad) {
 SALUN_EXPORT size_t salun_conv2d_bf16_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad) {
   if (!supported(C, K, R, stride, pad) || N < 1) return 0;
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
-  if (tn_route((int64_t)N * H * W, C, K, R, stride, pad)) {
-    // never 0 ("unsupported"): the column-sum partials of the bias gradient follow the GEMM's partials
-    size_t b = salun_gemm_bf16_tn_workspace_bytes((int64_t)N * H * W, K, C, 0);
-    b = (b + 255) & ~(size_t)255;
-    return b + (size_t)COLSUM_CHUNKS * K * sizeof(float);
-  }
   const int chunks = N * ((OH + 7) / 8) * ((OW + 7) / 8);
   const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
-  return (size_t)wgrad_splits(tiles, chunks) * R * R * K * C * sizeof(float) + (size_t)COLSUM_CHUNKS * K * sizeof(float);
+  const size_t tap = (size_t)wgrad_splits(tiles, chunks) * R * R * K * C * sizeof(float) + (size_t)COLSUM_CHUNKS * K * sizeof(float);
+  if (tn_route((int64_t)N * H * W, C, K, R, stride, pad)) {
+    // never 0 ("unsupported"): the column-sum partials of the bias gradient follow the GEMM's partials.  The larger
+    // of the two routes: a gradient pointer that is not 16-byte aligned (an odd-sized parameter ahead of it in the
+    // flat arena) takes the tap kernels at launch time, and this query does not see the pointer.
+    size_t b = salun_gemm_bf16_tn_workspace_bytes((int64_t)N * H * W, K, C, 0);
+    b = (b + 255) & ~(size_t)255;
+    b += (size_t)COLSUM_CHUNKS * K * sizeof(float);
+    return b > tap ? b : tap;
+  }
+  return tap;
 }
 
 // dw fp32 OIHW [K][C][R][R] (+= when accumulate); db fp32 [K] or null (the bias gradient, += when accumulate)
@@ -767,7 +771,7 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
   const size_t need = salun_conv2d_bf16_wgrad_workspace_bytes(N, H, W, C, K, R, stride, pad);
   if (ws_bytes < need) return SALUN_ENOSPC;
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
-  if (tn_route((int64_t)N * H * W, C, K, R, stride, pad)) {
+  if (tn_route((int64_t)N * H * W, C, K, R, stride, pad) && salun_aligned16(dw)) {  // else: the tap kernels take any dw
     const int64_t M = (int64_t)N * H * W;
     size_t gb = salun_gemm_bf16_tn_workspace_bytes(M, K, C, 0);
     const int rc = salun_gemm_bf16_tn(dy, x, dw, M, K, C, accumulate, 0, ws, gb, stream);

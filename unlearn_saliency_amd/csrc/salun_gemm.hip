@@ -989,11 +989,12 @@ int launch_gemm_bf16_r(const GbArgs &g0, hipStream_t st) {
   g.tiles_m = (g.M + BMt - 1) / BMt;
   g.tiles_n = g.N / BNt;
   const size_t ldsb = (size_t)NST * (BMt + BNt) * BK * 2;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
+  const int cfg_dev = salun_device_bit();
+  if (!((configured >> cfg_dev) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt_r<WGM, WGN, NST, BK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured = true;
+    configured |= 1ull << cfg_dev;
   }
   hipLaunchKernelGGL((k_gemm_bf16_nt_r<WGM, WGN, NST, BK>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
@@ -1210,11 +1211,12 @@ int launch_conv_ring(const IrArgs &g0, hipStream_t st) {
   g.tiles_m = (g.M + BMt - 1) / BMt;
   g.tiles_n = g.Kout / BNt;
   const size_t ldsb = (size_t)NST * (BMt + BNt) * 64;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
+  const int cfg_dev = salun_device_bit();
+  if (!((configured >> cfg_dev) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_bf16_ring<WGM, WGN, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured = true;
+    configured |= 1ull << cfg_dev;
   }
   hipLaunchKernelGGL((k_conv_bf16_ring<WGM, WGN, NST>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
@@ -1464,11 +1466,12 @@ TnPlan tn_plan(int64_t M, int Na, int Nb, int variant) {
 template <int WGA, int WGB, int RST, int NST>
 int launch_gemm_bf16_tn(const TnArgs &g, int splits, hipStream_t st) {
   const size_t ldsb = (size_t)NST * (64 * WGA + 64 * WGB) / 32 * RST * 64;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
+  const int cfg_dev = salun_device_bit();
+  if (!((configured >> cfg_dev) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_tn<WGA, WGB, RST, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured = true;
+    configured |= 1ull << cfg_dev;
   }
   hipLaunchKernelGGL((k_gemm_bf16_tn<WGA, WGB, RST, NST>), dim3(g.tiles_a * g.tiles_b * splits), dim3(64 * WGA * WGB), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
@@ -1510,11 +1513,12 @@ int launch_gemm_bf16(const GbArgs &g0, hipStream_t st) {
   g.tiles_m = (g.M + BMt - 1) / BMt;
   g.tiles_n = g.N / BNt;
   const size_t ldsb = (size_t)(DB ? 2 : 1) * (BMt + BNt) * 128;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
+  const int cfg_dev = salun_device_bit();
+  if (!((configured >> cfg_dev) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt<WGM, WGN, DB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured = true;
+    configured |= 1ull << cfg_dev;
   }
   hipLaunchKernelGGL((k_gemm_bf16_nt<WGM, WGN, DB>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
@@ -1528,11 +1532,12 @@ int launch_gemm_bf16_p(const GbArgs &g0, hipStream_t st) {
   g.tiles_m = (g.M + BMt - 1) / BMt;
   g.tiles_n = g.N / BNt;
   const size_t ldsb = (size_t)2 * (BMt + BNt) * 128;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
+  const int cfg_dev = salun_device_bit();
+  if (!((configured >> cfg_dev) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt_p<WGM, WGN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured = true;
+    configured |= 1ull << cfg_dev;
   }
   const int ntile = g.tiles_m * g.tiles_n;
   // 2 workgroups per CU (LDS: 2 x 64-80 KB); each walks a run of tiles inside its XCD's contiguous range

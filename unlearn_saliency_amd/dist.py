@@ -233,9 +233,21 @@ class BucketedGradReducer:
     def finish(self):
         # whatever backward did not complete (unused parameters; no backward at all on a rank with an empty shard) is
         # issued now, continuing the same descending order
+        late = 0
         while self._next >= 0:
             self._launch(self._next)
             self._next -= 1
+            late += 1
+        if late > 1 and any(self.arrived) and not getattr(self, "_warned", False):
+            # a backward ran, yet more than the head slice was left for finish(): a parameter that never receives a
+            # gradient (or receives several: arrived != expected, deliberately not launched early — the slice may
+            # still be written) holds back every slice below it.  Correct, but the overlap with backward is lost.
+            self._warned = True
+            import warnings
+            stuck = [b for b in range(len(self.bounds)) if self.arrived[b] != self.expected[b]]
+            warnings.warn(f"BucketedGradReducer: {late} of {len(self.bounds)} gradient slices were reduced after "
+                          f"backward (slices with arrivals != parameters: {stuck}); the all-reduce no longer overlaps "
+                          "backward")
         assert self._order == list(range(len(self.bounds) - 1, -1, -1)), self._order
         ws = world_size()
         for work, needs_div in self.works:

@@ -162,13 +162,13 @@ class FusedMaskedAdam(_FlatOptimizer):
         self.exp_avg_sq = arena.new_like()
         self.grad_clip = grad_clip
         self._sqnorm = torch.zeros(1, dtype=torch.float32, device=arena.device)
-        self._step_dev = None  # device-resident step counter (use_device_step): whole-step HIP graphs
+        self._step_dev = None  # device-resident step counter (use_device_step)
         self._coef = None
 
     def use_device_step(self) -> None:
-        """Keep Adam's step count (hence its bias corrections) on the device: a captured HIP graph replays the same
-        kernel arguments every step, so the host cannot pass t.  `steps` on the host keeps counting `step()` calls; a
-        graph replay advances only the device counter (graphs.StepGraph adds the host increment)."""
+        """Keep Adam's step count (hence its bias corrections) on the device (salun_adam_coefficients advances it and
+        derives the two step-dependent scalars there): the kernel arguments of a step are then the same every step.
+        `steps` on the host keeps counting `step()` calls."""
         if self._step_dev is None:
             self._step_dev = torch.tensor([self.steps], dtype=torch.int64, device=self.arena.device)
             self._coef = torch.zeros(2, dtype=torch.float32, device=self.arena.device)

@@ -2084,6 +2084,8 @@ inline int wgrad_nsplit(int K, int C, int nchunks) {
   const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
   // one workgroup per CU is resident (register budget): a single full round of 256 workgroups, each with a long
   // run of chunks, beats more and shorter splits (prologue/epilogue and partial-sum traffic scale with nsplit)
+  // (round 5 sweep on the ResNet-18 step, profiles/r05_wgrad_sweep.txt: 128 / 192 / 256 / 384 / 512 target workgroups
+  // -> 94.4 / 107.3 / 114.7 / 103.4 / 106.1 steps/s)
   int ns = (256 + tiles - 1) / tiles;
   if (ns > nchunks) ns = nchunks;
   if (ns < 1) ns = 1;

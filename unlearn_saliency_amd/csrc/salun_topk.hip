@@ -331,8 +331,15 @@ __device__ __forceinline__ void wave_sum_rows(const uint16_t *__restrict__ rows,
                                               uint32_t *c_even, uint32_t *c_odd) {
   const uint32_t *base = reinterpret_cast<const uint32_t *>(rows);
   uint32_t a = 0, b = 0;
-#pragma unroll 8
-  for (int g = 0; g < grid; ++g) {
+  int g = 0;
+  for (; g + 32 <= grid; g += 32) {  // 32 independent loads in flight per lane
+    uint32_t v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = base[((size_t)(g + i) * nk + j) * (BINS_A / 2) + lane];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { a += v[i] & 0xFFFFu; b += v[i] >> 16; }
+  }
+  for (; g < grid; ++g) {
     const uint32_t v = base[((size_t)g * nk + j) * (BINS_A / 2) + lane];
     a += v & 0xFFFFu;
     b += v >> 16;

@@ -11,15 +11,15 @@ for cfg in "n18 1" "n18 10" "nd 1" "nd 10" "ns 1"; do
 done
 for cfg in "n18 1" "n18 10" "nd 1" "ns 1"; do
   set -- $cfg
-  KEEP_TRACE=0 timeout 300 bash tools/prof.sh r05f_topk_$1_$2 python tools/topk_prof.py $1 $2 10 > /dev/null 2>&1
+  KEEP_TRACE=0 timeout 300 bash tools/prof.sh r05j_topk_$1_$2 python tools/topk_prof.py $1 $2 10 > /dev/null 2>&1
 done
 python - <<'PY'
 import csv, glob
-for f in sorted(glob.glob("gpurun_out/r05f_*_kernel_stats.csv")):
+for f in sorted(glob.glob("gpurun_out/r05j_*_kernel_stats.csv")):
     row = {}
     for r in csv.DictReader(open(f)):
         n = r["Name"]
         if "k_" in n and not any(s in n for s in ("fill", "popcount", "partials")):
             row[n.split("::")[1].split("(")[0]] = float(r["AverageNs"]) / 1e3
-    print(f.split("r05f_")[1].split("_kernel")[0].ljust(14), "  ".join(f"{k[2:14]} {v:6.2f}" for k, v in sorted(row.items())), " sum %.1f" % sum(row.values()))
+    print(f.split("r05j_")[1].split("_kernel")[0].ljust(14), "  ".join(f"{k[2:14]} {v:6.2f}" for k, v in sorted(row.items())), " sum %.1f" % sum(row.values()))
 PY

@@ -43,9 +43,19 @@
 #include <cmath>
 #include <cstdlib>
 
+// Timing switches (0 in the product build; profiles/r05_topk_experiments.txt was measured with run-time versions of
+// them — results are WRONG with any bit set, they only show where a kernel's time goes):
+//   k_main    8 no compaction   16 no mask stores   32 no software prefetch of the next chunk
+//   k_resolve 1 stop after the row sums   2 ... after the selection   4 no flush of the second-level histogram
+//   k_finish 64 stop after the prologue loads   128 ... after the two scans
+#ifndef SALUN_TOPK_EXP
+#define SALUN_TOPK_EXP 0
+#endif
+
 namespace {
 
 constexpr int MAXK = SALUN_MAX_THRESHOLDS;
+constexpr int TOPK_EXP = SALUN_TOPK_EXP;
 constexpr int D0_BINS = 2048;  // key >> 20
 constexpr int CHUNK_VEC = 4 * SALUN_BLOCK;  // float4 per chunk (4 sub-vectors per lane)
 constexpr int CHUNK = CHUNK_VEC * 4;        // 4096 elements: streaming / tie-ordering granule
@@ -97,6 +107,8 @@ struct FastState {
   u64 zt_budget[MAXK];   // > 0: the threshold is the zero key; this many zeros (lowest flat index first) are selected
   uint32_t zt_any;       // some zt_budget is set -> the tie pass behind k_finish runs
   uint32_t spill_cnt[MAXK];  // entries in the threshold's shared spill row (candidates a full slab could not take)
+  uint32_t fin_n[MAXK];      // k_finish: residents of the final bin gathered so far (its workgroups append)
+  uint32_t fin_ticket[MAXK]; // k_finish: workgroups of the threshold that are done gathering
   uint32_t fail;         // -> the full scan redoes the job
   uint32_t hist2[MAXK][HIST2_BINS];
 };
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
                                                       uint32_t *__restrict__ slab_cnt, uint32_t *__restrict__ wg_gt,
                                                       uint16_t *__restrict__ rows, uint32_t *__restrict__ wg_zero,
                                                       uint32_t *__restrict__ wg_min, uint2 *__restrict__ spill,
-                                                      uint32_t cap, uint32_t spill_cap, int nk_real, int exp) {
+                                                      uint32_t cap, uint32_t spill_cap, int nk_real) {
   constexpr bool MULTI = NK > 2;
   constexpr bool store = STORE;
   __shared__ uint32_t s_hist[NK][BINS_A];
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
     for (int u = 0; u < 4; ++u) {
       k[u][0] = key_of(x[u].x); k[u][1] = key_of(x[u].y); k[u][2] = key_of(x[u].z); k[u][3] = key_of(x[u].w);
     }
-    if (exp & 32) {  // (timing experiment: no software prefetch — load this chunk now)
+    if (TOPK_EXP & 32) {  // (timing experiment: no software prefetch — load this chunk now)
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         x[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(acc) + c * CHUNK_VEC + u * SALUN_BLOCK + tid);
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
       }
     }
     const int64_t cn = c + gridDim.x;
-    if (cn < nfull && !(exp & 32)) {  // the next chunk's loads fly while this one is classified
+    if (cn < nfull && !(TOPK_EXP & 32)) {  // the next chunk's loads fly while this one is classified
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         x[u] = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(acc) + cn * CHUNK_VEC + u * SALUN_BLOCK + tid);
@@ -563,11 +575,11 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
             jsel[u][e] = ((k[u][e] - lo[j]) <= w) ? (uint32_t)j : jsel[u][e];
             gtc[j] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(k[u][e] > hi[j]));
           }
-          if (!VO && !(exp & 16))
+          if (!VO && !(TOPK_EXP & 16))
             __builtin_nontemporal_store(bits, reinterpret_cast<uint32_t *>(mp.m[j]) + c * CHUNK_VEC + u * SALUN_BLOCK + tid);
         }
       }
-      if (!(exp & 8)) {
+      if (!(TOPK_EXP & 8)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -607,10 +619,10 @@ __global__ __launch_bounds__(SALUN_BLOCK) void k_main(const float *__restrict__ 
           total += (uint32_t)__builtin_popcountll(bal[u * 4 + e]);
           gtc[j] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(k[u][e] > hi[j]));
         }
-        if (!VO && !(exp & 16))
+        if (!VO && !(TOPK_EXP & 16))
           __builtin_nontemporal_store(bits, reinterpret_cast<uint32_t *>(mp.m[j]) + c * CHUNK_VEC + u * SALUN_BLOCK + tid);
       }
-      if (total && !(exp & 8)) {  // wave-uniform
+      if (total && !(TOPK_EXP & 8)) {  // wave-uniform
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&s_cnt[j], total);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
                                                   const uint32_t *__restrict__ wg_zero, const uint2 *__restrict__ spill,
                                                   uint32_t cap, uint32_t spill_cap, int main_grid, int nk, int nseg,
                                                   uint32_t seg_cap, uint2 *__restrict__ list2 /*[nk][nseg][seg_cap]*/,
-                                                  uint32_t *__restrict__ seg_cnt /*[nk][nseg]*/, MaskPtrs mp, int exp) {
+                                                  uint32_t *__restrict__ seg_cnt /*[nk][nseg]*/, MaskPtrs mp) {
   __shared__ uint32_t s_part[16][BINS_A];
   __shared__ uint32_t s_hist[BINS_A];
   __shared__ u64 s_gtw[16], s_zw[16];
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
   }
   if (failed) return;  // already decided (a u16 row counter wrapped in k_main): the full scan redoes the job
   if (mode != MODE_GE) return;  // nothing / everything selected: no candidates, k_finish publishes
-  if (exp & 1) return;  // (timing experiment: loads + row sums only)
+  if (TOPK_EXP & 1) return;  // (timing experiment: loads + row sums only)
   if (tid == 0) { s_n = 0; s_ok = 0; }
   for (int i = tid; i < HIST2_BINS; i += 1024) s_h2[i] = 0;
   __syncthreads();
@@ -868,7 +880,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
   }
   __syncthreads();
   uint2 *seg = list2 + ((size_t)j * nseg + g) * seg_cap;
-  if (exp & 2) return;  // (timing experiment: ... + selection)
+  if (TOPK_EXP & 2) return;  // (timing experiment: ... + selection)
   if (s_ok) {
     const uint32_t lo2 = s_lo2, hi2 = s_hi2, sh2 = s_sh2;
     uint8_t *mask = mp.m[j];
@@ -922,7 +934,7 @@ __global__ __launch_bounds__(1024) void k_resolve(FastState *fs, const uint2 *__
   }
   __syncthreads();
   const uint32_t m = s_n;
-  if (m && !(exp & 4))
+  if (m && !(TOPK_EXP & 4))
     for (int i = tid; i < HIST2_BINS; i += 1024)
       if (s_h2[i]) atomicAdd(&fs->hist2[j][i], s_h2[i]);
   if (tid == 0) {
@@ -946,15 +958,24 @@ __device__ __forceinline__ const uint2 *list_entry_ptr(const uint2 *__restrict__
   return lst + (size_t)a * seg_cap + (f - s_off[a]);
 }
 
+// F workgroups of 1024 threads per threshold (F = 1 for short lists).  Each repeats the two small scans (segment
+// offsets, second-level histogram -> final bin), walks ITS share of the short-list segments — entries outside the final
+// bin are final and only need their mask byte when k_main's guess was wrong — and appends the few residents of the final
+// bin to one global list with write-through (sc1) stores; the workgroup that takes the last ticket ranks them exactly
+// (key descending, flat index ascending) and publishes tau_j.  Hand-off form (MI355X_MICROARCH.md, "valid forms"): sc1
+// payload -> s_waitcnt vmcnt(0) -> device-scope ticket; the last arriver reads the payload with sc1 loads — no fence,
+// so no write-back of the masks k_main left dirty in the L2s.
 template <bool VO>
 __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, const uint2 *__restrict__ list2,
                                                  const uint32_t *__restrict__ seg_cnt, int nseg, uint32_t seg_cap,
-                                                 const uint32_t *__restrict__ wg_min, int main_grid, MaskPtrs mp, int exp) {
+                                                 const uint32_t *__restrict__ wg_min, int main_grid, u64 *fin_list, int nk,
+                                                 MaskPtrs mp) {
   __shared__ uint32_t s_w[16];
   __shared__ uint32_t s_off[MAX_SEGS], s_cl[MAX_SEGS];
   __shared__ uint32_t s_key[FINAL_CAP], s_idx[FINAL_CAP];
-  __shared__ uint32_t s_b2, s_r3, s_c3, s_found, s_n, s_tau, s_hist[2048], s_sel, s_rem;
-  const int j = blockIdx.x, tid = threadIdx.x;
+  __shared__ uint32_t s_b2, s_r3, s_c3, s_found, s_tau, s_hist[2048], s_sel, s_rem, s_last, s_n, s_base;
+  const int j = blockIdx.x % nk, f = blockIdx.x / nk, F = gridDim.x / nk;
+  const int tid = threadIdx.x;
   // ---- one round trip for everything the prologue needs
   const uint32_t failed = fs->fail, mode = fs->mode[j], was_all = fs->was_all[j];
   const u64 ztb = fs->zt_budget[j], r2 = fs->r2[j];
@@ -967,10 +988,11 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
   for (int b = tid; b < main_grid; b += 1024) { const uint32_t v = wg_min[b]; wmin = v < wmin ? v : wmin; }
   if (failed) return;  // the full scan publishes
   if (mode == MODE_NONE) {
-    if (tid == 0) { pub->mode[j] = MODE_NONE; pub->tau[j] = 0; pub->route = 1; }
+    if (tid == 0 && f == 0) { pub->mode[j] = MODE_NONE; pub->tau[j] = 0; pub->route = 1; }
     return;
   }
   if (mode == MODE_ALL) {  // k >= n: every element is selected; for k == n the threshold is the smallest key
+    if (f != 0) return;
     uint32_t m = wmin;
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(m, off, 64); m = o < m ? o : m; }
     if ((tid & 63) == 0) s_w[tid >> 6] = m;
@@ -984,11 +1006,11 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
     return;
   }
   if (ztb != 0) {  // the threshold is the zero key; the tie pass writes the admitted zeros
-    if (tid == 0) { pub->mode[j] = MODE_GE; pub->tau[j] = ZERO_KEY; pub->route = 1; }
+    if (tid == 0 && f == 0) { pub->mode[j] = MODE_GE; pub->tau[j] = ZERO_KEY; pub->route = 1; }
     return;
   }
-  if (exp & 64) return;  // (timing experiment: prologue loads only)
-  if (tid == 0) { s_found = 0; s_n = 0; s_tau = 0; }
+  if (TOPK_EXP & 64) return;  // (timing experiment: prologue loads only)
+  if (tid == 0) { s_found = 0; s_tau = 0; s_last = 0; s_n = 0; s_base = 0; }
   uint32_t n2;
   {  // offsets of the per-workgroup segments of the short list
     const uint32_t ex = block1024_excl_scan(segc, s_w, &n2);
@@ -1019,7 +1041,7 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
     }
   }
   __syncthreads();
-  if (exp & 128) return;  // (timing experiment: ... + the two scans)
+  if (TOPK_EXP & 128) return;  // (timing experiment: ... + the two scans)
   uint32_t lo3 = lo2 + (s_b2 << sh2);
   uint32_t hi3 = lo3 + ((1u << sh2) - 1u);
   if (hi3 > hi2 || hi3 < lo3) hi3 = hi2;
@@ -1029,27 +1051,30 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
   uint8_t *mask = mp.m[j];
   if (c3 <= (uint32_t)FINAL_CAP) {
     // one wave per segment, eight segments (two entries per lane each) in flight per wave: coalesced loads, no search
-    // for the segment of an entry
+    // for the segment of an entry; workgroup f of F takes segments f, f + F, f + 2F, ...
+    u64 *fin = fin_list + (size_t)j * FINAL_CAP;
     auto settle = [&](const uint2 e) {
       if (e.x > hi3) { if (!VO && e.x <= mid) mask[e.y] = 1; }
       else if (e.x < lo3) { if (!VO && e.x > mid) mask[e.y] = 0; }
       else {
-        const uint32_t p = atomicAdd(&s_n, 1u);
+        const uint32_t p = atomicAdd(&s_n, 1u);  // this workgroup's residents of the final bin (a handful)
         if (p < (uint32_t)FINAL_CAP) { s_key[p] = e.x; s_idx[p] = e.y; }
       }
     };
     const int wave = tid >> 6, lane = tid & 63;
-    for (int sg0 = wave; sg0 < nseg; sg0 += 128) {
+    const int nmine = (nseg - f + F - 1) / F;  // segments of this workgroup: f + F * i, i < nmine
+    for (int i0 = wave; i0 < nmine; i0 += 128) {
       uint2 e[8][2];
       uint32_t cn[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int sg = sg0 + 16 * q;
-        cn[q] = (sg < nseg) ? s_cl[sg] : 0u;
+        const int i = i0 + 16 * q;
+        const int sg = f + F * i;
+        cn[q] = (i < nmine) ? s_cl[sg] : 0u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const uint32_t i = (uint32_t)lane + 64u * (uint32_t)h;
-          e[q][h] = (i < cn[q]) ? lst[(size_t)sg * seg_cap + i] : make_uint2(KEY_SKIP, 0u);
+          const uint32_t li = (uint32_t)lane + 64u * (uint32_t)h;
+          e[q][h] = (li < cn[q]) ? lst[(size_t)sg * seg_cap + li] : make_uint2(KEY_SKIP, 0u);
         }
       }
 #pragma unroll
@@ -1057,12 +1082,42 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           if (e[q][h].x != KEY_SKIP) settle(e[q][h]);
-        for (uint32_t i = 128u + (uint32_t)lane; i < cn[q]; i += 64u) settle(lst[(size_t)(sg0 + 16 * q) * seg_cap + i]);
+        for (uint32_t li = 128u + (uint32_t)lane; li < cn[q]; li += 64u)
+          settle(lst[(size_t)(f + F * (i0 + 16 * q)) * seg_cap + li]);
       }
     }
     __syncthreads();
-    const uint32_t L = s_n;
-    if (L != c3) { if (tid == 0) fs->fail = 1; return; }
+    uint32_t L = s_n;
+    if (F > 1) {
+      // ---- hand this workgroup's residents to whichever workgroup of the threshold finishes last
+      if (L > (uint32_t)FINAL_CAP) L = FINAL_CAP;  // (cannot happen: c3 <= FINAL_CAP is the total)
+      if (tid == 0) s_base = L ? atomicAdd(&fs->fin_n[j], L) : 0u;
+      __syncthreads();
+      const uint32_t base = s_base;
+      for (uint32_t p = tid; p < L; p += 1024)
+        if (base + p < (uint32_t)FINAL_CAP)
+          __hip_atomic_store(&fin[base + p], ((u64)s_idx[p] << 32) | (u64)s_key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have left
+      __syncthreads();
+      if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(&fs->fin_ticket[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (uint32_t)(F - 1)) ? 1u : 0u;
+      }
+      __syncthreads();
+      if (!s_last) return;
+      // ---- the last workgroup of this threshold: every resident of the final bin is in the list
+      L = __hip_atomic_load(&fs->fin_n[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (L != c3) { if (tid == 0) fs->fail = 1; return; }
+      for (uint32_t p = tid; p < L; p += 1024) {
+        const u64 v = __hip_atomic_load(&fin[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_key[p] = (uint32_t)v;
+        s_idx[p] = (uint32_t)(v >> 32);
+      }
+    } else if (L != c3) {
+      if (tid == 0) fs->fail = 1;
+      return;
+    }
+    __syncthreads();
     for (uint32_t p = tid; p < L; p += 1024) {
       const uint32_t kp = s_key[p], ip = s_idx[p];
       uint32_t rank = 0;
@@ -1074,14 +1129,15 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
     if (tid == 0) { pub->mode[j] = MODE_GE; pub->tau[j] = s_tau; pub->route = 1; }
     return;
   }
+  if (f != 0) return;  // a crowded final bin (ties): one workgroup walks the whole list below
   if (sh2 != 0) {
     // ---- a crowded final bin that still spans 2^sh2 keys (a run of ties inside it): one more histogram, one counter
     // per key, narrows it to the single key holding the rank
     if (sh2 > 11) { if (tid == 0) fs->fail = 1; return; }  // (wider than the counters below: never for a real bracket)
     for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
     __syncthreads();
-    for (uint32_t f = tid; f < n2; f += 1024) {
-      const uint2 e = *list_entry_ptr(lst, s_off, nseg, seg_cap, f);
+    for (uint32_t ff = tid; ff < n2; ff += 1024) {
+      const uint2 e = *list_entry_ptr(lst, s_off, nseg, seg_cap, ff);
       if (e.x >= lo3 && e.x <= hi3) atomicAdd(&s_hist[e.x - lo3], 1u);
     }
     __syncthreads();
@@ -1105,8 +1161,8 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
     const int nb = (level == 2) ? 1024 : 2048;
     for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
     __syncthreads();
-    for (uint32_t f = tid; f < n2; f += 1024) {
-      const uint2 e = *list_entry_ptr(lst, s_off, nseg, seg_cap, f);
+    for (uint32_t ff = tid; ff < n2; ff += 1024) {
+      const uint2 e = *list_entry_ptr(lst, s_off, nseg, seg_cap, ff);
       if (e.x != lo3) continue;
       const bool match = (level == 0) || (level == 1 ? (e.y >> 21) == prefix : (e.y >> 10) == prefix);
       if (match) atomicAdd(&s_hist[(e.y >> shift) & (uint32_t)(nb - 1)], 1u);
@@ -1126,8 +1182,8 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
   }
   const uint32_t idx_star = prefix;  // the r3-th lowest index among the ties
   if (!VO)
-    for (uint32_t f = tid; f < n2; f += 1024) {
-      const uint2 e = *list_entry_ptr(lst, s_off, nseg, seg_cap, f);
+    for (uint32_t ff = tid; ff < n2; ff += 1024) {
+      const uint2 e = *list_entry_ptr(lst, s_off, nseg, seg_cap, ff);
       const bool fin = e.x > hi3 || (e.x == lo3 && e.y <= idx_star);
       if (fin != (e.x > mid)) mask[e.y] = (uint8_t)fin;
     }
@@ -1652,9 +1708,8 @@ inline int sample_size(int64_t n) {
   return S;
 }
 inline int main_grid_for(int64_t n) {
-  static const int mg = [] { const char *e = getenv("SALUN_TOPK_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : MAIN_GRID; }();
   const int64_t nfull = n / CHUNK;
-  return (int)(nfull < mg ? (nfull < 1 ? 1 : nfull) : mg);
+  return (int)(nfull < MAIN_GRID ? (nfull < 1 ? 1 : nfull) : MAIN_GRID);
 }
 // worst-case (p = 1/2) share of the values inside one bracket, for sizing: 2 * margin / S plus the bin-edge slack
 inline double bracket_fraction(int64_t S) {
@@ -1669,7 +1724,8 @@ struct FastLayout {
   uint32_t cap;      // slab entries per (workgroup, threshold)
   uint32_t spill_cap;  // entries of one threshold's shared spill row
   uint32_t seg_cap;  // short-list entries per k_resolve workgroup
-  size_t off_fs, off_keys, off_cnt, off_gt, off_rows, off_zero, off_min, off_slabs, off_spill, off_list2, off_seg, bytes;
+  int gf;            // k_finish workgroups per threshold
+  size_t off_fs, off_keys, off_cnt, off_gt, off_rows, off_zero, off_min, off_slabs, off_spill, off_list2, off_seg, off_fin, bytes;
 };
 inline FastLayout fast_layout(int64_t n, int nk, double f) {
   FastLayout L;
@@ -1685,10 +1741,6 @@ inline FastLayout fast_layout(int64_t n, int nk, double f) {
   // four slab entries (one unrolled round of loads), at most 512 workgroups (2 per CU) in all
   int gpj = (int)(cands / 4096.0) + 1;
   if (gpj > 512 / nk) gpj = 512 / nk;
-  {
-    static const int gr_cap = [] { const char *e = getenv("SALUN_TOPK_GR"); return e ? atoi(e) : 0; }();
-    if (gr_cap > 0 && gpj > gr_cap) gpj = gr_cap;  // (timing experiments)
-  }
   if (gpj < 1) gpj = 1;
   L.gr = gpj;
   // residents of the chosen first-level bin, spread over the segments.  Their mean is cands / BINS_A / gpj, but a layer
@@ -1707,6 +1759,11 @@ inline FastLayout fast_layout(int64_t n, int nk, double f) {
   L.off_spill = b; b += align256(sizeof(uint2) * (size_t)nk * (size_t)L.spill_cap);
   L.off_list2 = b; b += align256(sizeof(uint2) * (size_t)nk * (size_t)L.gr * (size_t)L.seg_cap);
   L.off_seg = b;   b += align256(sizeof(uint32_t) * (size_t)nk * (size_t)L.gr);
+  L.off_fin = b;   b += align256(sizeof(u64) * (size_t)nk * (size_t)FINAL_CAP);
+  L.gf = (gpj + 63) / 64;  // one k_finish workgroup per 64 segments, at most 8 (and 128 in all)
+  if (L.gf > 8) L.gf = 8;
+  if (L.gf > 128 / nk) L.gf = 128 / nk;
+  if (L.gf < 1) L.gf = 1;
   L.bytes = b;
   return L;
 }
@@ -1766,17 +1823,13 @@ inline int fullscan_grid(int64_t n) {
   return (int)g;
 }
 
-inline int topk_exp() {
-  static const int v = [] { const char *e = getenv("SALUN_TOPK_EXP"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
 // Typed views of one fast-route instance inside the workspace.
 struct FastPtrs {
   FastState *fs;
   uint32_t *keys, *slab_cnt, *wg_gt, *wg_zero, *wg_min, *seg_cnt;
   uint16_t *rows;
   uint2 *slabs, *spill, *list2;
+  u64 *fin;
 };
 inline FastPtrs fast_ptrs(char *base, const FastLayout &L) {
   FastPtrs P;
@@ -1791,6 +1844,7 @@ inline FastPtrs fast_ptrs(char *base, const FastLayout &L) {
   P.spill = reinterpret_cast<uint2 *>(base + L.off_spill);
   P.list2 = reinterpret_cast<uint2 *>(base + L.off_list2);
   P.seg_cnt = reinterpret_cast<uint32_t *>(base + L.off_seg);
+  P.fin = reinterpret_cast<u64 *>(base + L.off_fin);
   return P;
 }
 
@@ -1799,7 +1853,7 @@ inline void launch_main(int nk, const FastLayout &L, const FastPtrs &P, hipStrea
                         const MaskPtrs &mp) {
 #define SALUN_MAIN(NKT)                                                                                                 \
   hipLaunchKernelGGL((k_main<NKT, VO, STORE>), dim3(L.grid), dim3(SALUN_BLOCK), 0, st, acc, n, P.fs, mp, P.slabs,       \
-                     P.slab_cnt, P.wg_gt, P.rows, P.wg_zero, P.wg_min, P.spill, L.cap, L.spill_cap, nk, topk_exp())
+                     P.slab_cnt, P.wg_gt, P.rows, P.wg_zero, P.wg_min, P.spill, L.cap, L.spill_cap, nk)
   if (nk <= 1) SALUN_MAIN(1);
   else if (nk <= 2) SALUN_MAIN(2);
   else if (nk <= 3) SALUN_MAIN(3);
@@ -1823,17 +1877,17 @@ inline int run_fast_tail(const float *acc, int64_t n, const KList &kl, const Mas
   SALUN_LAUNCH_CHECK();
   if (values_only)
     hipLaunchKernelGGL(k_resolve<true>, dim3(L.gr * nk), dim3(1024), 0, st, P.fs, P.slabs, P.slab_cnt, P.wg_gt, P.rows,
-                       P.wg_zero, P.spill, L.cap, L.spill_cap, L.grid, nk, L.gr, L.seg_cap, P.list2, P.seg_cnt, mp, topk_exp());
+                       P.wg_zero, P.spill, L.cap, L.spill_cap, L.grid, nk, L.gr, L.seg_cap, P.list2, P.seg_cnt, mp);
   else
     hipLaunchKernelGGL(k_resolve<false>, dim3(L.gr * nk), dim3(1024), 0, st, P.fs, P.slabs, P.slab_cnt, P.wg_gt, P.rows,
-                       P.wg_zero, P.spill, L.cap, L.spill_cap, L.grid, nk, L.gr, L.seg_cap, P.list2, P.seg_cnt, mp, topk_exp());
+                       P.wg_zero, P.spill, L.cap, L.spill_cap, L.grid, nk, L.gr, L.seg_cap, P.list2, P.seg_cnt, mp);
   SALUN_LAUNCH_CHECK();
   if (values_only)
-    hipLaunchKernelGGL(k_finish<true>, dim3(nk), dim3(1024), 0, st, P.fs, pub, P.list2, P.seg_cnt, L.gr, L.seg_cap,
-                       P.wg_min, L.grid, mp, topk_exp());
+    hipLaunchKernelGGL(k_finish<true>, dim3(nk * L.gf), dim3(1024), 0, st, P.fs, pub, P.list2, P.seg_cnt, L.gr, L.seg_cap,
+                       P.wg_min, L.grid, P.fin, nk, mp);
   else
-    hipLaunchKernelGGL(k_finish<false>, dim3(nk), dim3(1024), 0, st, P.fs, pub, P.list2, P.seg_cnt, L.gr, L.seg_cap,
-                       P.wg_min, L.grid, mp, topk_exp());
+    hipLaunchKernelGGL(k_finish<false>, dim3(nk * L.gf), dim3(1024), 0, st, P.fs, pub, P.list2, P.seg_cnt, L.gr, L.seg_cap,
+                       P.wg_min, L.grid, P.fin, nk, mp);
   SALUN_LAUNCH_CHECK();
   const size_t lds_bytes = D0_BINS + sizeof(uint32_t) * (size_t)(nk < 2 ? 2 : nk) * 1024;
   hipLaunchKernelGGL(k_fullscan, dim3(fullscan_grid(n)), dim3(SALUN_BLOCK), lds_bytes, st, acc, n, kl, mp, pub, full, P.fs,

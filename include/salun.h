@@ -83,11 +83,14 @@ int salun_saliency_accumulate(float *acc /*dev*/, const float *g /*dev*/,
  * 1 <= nk <= SALUN_MAX_THRESHOLDS.
  * Algorithmic traffic: 4 B read + nk B written per element.
  * Implementation (csrc/salun_topk.hip): for n >= 8192 and 16-B aligned input the vector is read ONCE — a hashed
- * sample brackets every threshold, one streaming pass writes the masks outside the brackets and compacts the ~5 % of
- * elements inside them, and the exact threshold is resolved among those candidates; a persistent full-scan radix
- * select (3 histogram passes + 1 write pass, grid barriers) handles small / unaligned inputs and is the device-side
- * fallback when a bracket misses or a candidate buffer overflows (heavy ties) — the resulting mask is the same
- * function of the input either way.
+ * sample brackets every threshold, one streaming pass writes the masks outside the brackets and compacts the ~4 % of
+ * elements inside them, and the exact threshold is resolved among those candidates.  k >= n selects everything without
+ * a select; exact zeros (a real accumulator holds several per cent of them) are counted instead of compacted, and a
+ * threshold that lands among them is finished by a tie pass in flat-index order; candidates a workgroup's slab cannot
+ * take (a layer whose magnitudes sit at the threshold) go to a shared spill row.  A persistent full-scan radix select
+ * (3 histogram passes + 1 write pass, grid barriers) handles small / unaligned inputs and is the device-side fallback
+ * when a bracket misses, heavy ties at a non-zero key overflow a buffer, or a threshold lies among NaNs — the resulting
+ * mask is the same function of the input either way.
  * salun_mask_topk_ex takes flags:
  *   SALUN_TOPK_FORCE_FULL_SCAN  skip the single-read route (tests / A-B timing)
  *   SALUN_TOPK_VALUES_ONLY      no masks are written (masks_out may be NULL); only the thresholds are published
@@ -180,7 +183,7 @@ int salun_masked_adam_step(float *p /*dev*/, const float *g /*dev*/, float *m1 /
                            double gscale, double lr, double b1, double b2, double eps,
                            double wd, int step, int64_t n, salun_stream_t stream);
 
-/* The same step with its step-dependent scalars taken from DEVICE memory — for whole-step HIP graphs, which replay
+/* The same step with its step-dependent scalars taken from DEVICE memory — for callers that replay
  * identical kernel arguments every step (the host cannot pass t):
  *   salun_adam_coefficients: ++(*step) on the stream, then coef = { sqrt(1 - b2^t), -lr / (1 - b1^t) } in the same
  *     double arithmetic as salun_masked_adam_step;

@@ -370,6 +370,7 @@ class Diffusion(object):
         where the clip sees the sum of both gradients.  Returns (loss, forgetting_loss, ewc_loss) tensors."""
         args, config = self.args, self.config
         b = self.betas
+        draws.next_step()  # dropout keys are (step, call index): every training step advances the step (ADVICE r4)
         x_remember, c_remember = remember_batch
         x_remember, c_remember = x_remember.to(self.device), c_remember.to(self.device)
         x_remember = data_transform(config, x_remember)

@@ -107,8 +107,10 @@ def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch
     if values_only:
         out, marr = [], None
     else:
-        if out is None:
-            out = [torch.empty(n, dtype=torch.uint8, device=acc.device) for _ in ks]
+        if out is None:  # one allocation for all thresholds: the masks are rows of it, each row 256-byte aligned (the
+            # single-read route stores the masks as dwords)
+            n_pad = (n + 255) & ~255
+            out = [r[:n] for r in torch.empty((nk, n_pad), dtype=torch.uint8, device=acc.device).unbind(0)]
         assert len(out) == nk and all(o.numel() == n for o in out)
         marr = (c_void_p * nk)(*[_dev(o, torch.uint8, "mask").value for o in out])
     nbytes = L.salun_mask_topk_workspace_bytes(c_int64(n), c_int(nk))

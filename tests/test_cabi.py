@@ -123,3 +123,26 @@ def test_k16_domain_and_workspace_queries_are_host_only(built_lib):
     gemm = tnws(c_int64(8 * 64 * 64), 320, 320, 0)
     assert w(8, 64, 64, 320, 320, 1, 1, 0) >= gemm > 0
     assert w(8, 64, 64, 320, 320, 3, 1, 1) > 0 and w(8, 64, 64, 4, 320, 3, 1, 1) == 0
+
+
+def test_topk_workspace_query_is_host_only_and_sized_for_real_accumulators(built_lib):
+    """`salun_mask_topk_workspace_bytes` is host arithmetic (no device call).  Its sizes follow the single-read route's
+    layout: slabs of twice the mean candidate share per workgroup, a spill row and short-list segments for half of all
+    candidates of a threshold — so they grow about linearly in nk, stay a small multiple of the vector for one threshold,
+    and the arguments the C-ABI refuses give 0."""
+    from ctypes import c_int64
+    from unlearn_saliency_amd import _lib
+    q = lambda n, nk: _lib.lib().salun_mask_topk_workspace_bytes(c_int64(n), nk)
+    N18, ND, NS = 11_173_962, 38_632_323, 859_520_964
+    assert q(0, 1) > 0 and q(1, 1) > 0 and q(8191, 1) > 0            # the full scan's state alone
+    assert q(-1, 1) == 0 and q(N18, 0) == 0 and q(N18, _lib.SALUN_MAX_THRESHOLDS + 1) == 0
+    for n in (8192, N18, ND, NS):
+        one = q(n, 1)
+        assert one < 4 * n + (4 << 20)                                # one threshold: well under the vector itself
+        assert q(n, 2) > one
+    assert q(N18, 10) < 16 * q(N18, 1) and q(ND, 10) < 16 * q(ND, 1)
+    # the reference's calls: ten ratios on a ResNet-18, one ratio on the diffusion U-Nets
+    assert q(N18, 10) < 256 << 20 and q(ND, 1) < 64 << 20 and q(NS, 1) < 256 << 20
+    # 2^27 is where the brackets switch to the 2^20-element sample (a ~8x narrower bracket): the workspace of ONE
+    # threshold drops across that boundary although the vector grows
+    assert q((1 << 27) + 8, 1) < q((1 << 27) - 8, 1)

@@ -20,6 +20,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 NS = 859_520_964
+
+
+def _pmc_adam_traffic():
+    """HBM bytes of one salun_masked_adam_step launch at N_S from the committed PMC passes: a CONSTANT (counters cannot be
+    collected inside a timed run), labelled as such."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rnd in ("r05", "r04", "r02"):
+        pth = os.path.join(root, "profiles", f"{rnd}_pmc_traffic.json")
+        try:
+            with open(pth) as f:
+                t = json.load(f)["kernels"][f"k_masked_adam@{rnd}_ns"]["traffic_bytes"]
+            return t, (f"constant from profiles/{rnd}_pmc_traffic.json (k_masked_adam at N_S; rocprofv3 --pmc FETCH_SIZE / "
+                       f"WRITE_SIZE in separate passes, tools/pmc.sh) — not measured in this run")
+        except Exception:
+            continue
+    return None, None
+
 FWD_TFLOP_PER_SAMPLE = 0.803  # SURVEY.md §8 D2 (FlopCounterMode on the reference module)
 
 
@@ -168,7 +185,8 @@ def main(argv=None):
                      "topk_GBps_algorithmic": 5.0 * NS / (topk_ms * 1e-3) / 1e9},
         "roofline": {"kernel": "salun_masked_adam_step @ N_S" + ("" if not sdist.collectives_on() else
                                                                   " (+ gradient-bucket join)"),
-                     "traffic": None, "bound": "hbm", "algorithmic_bytes": 29 * NS,
+                     "traffic": _pmc_adam_traffic()[0], "traffic_source": _pmc_adam_traffic()[1],
+                     "bound": "hbm", "algorithmic_bytes": 29 * NS,
                      "mean_launch_ms": tail_ms, "achieved": 29.0 * NS / (tail_ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": 29.0 * NS / (tail_ms * 1e-3) / 1e9 / 8000.0},
         "fwd_bwd": {"tflop_per_step": tflop, "achieved_TFLOPs": tflop / dt,

@@ -12,7 +12,7 @@ import csv, json, os, sys
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALG = {"k_masked_sgd_vec": 21, "k_masked_adam": 29, "k_saliency_accumulate": 12, "k_sqnorm_partial": 4}
-TOPK = ("k_sample", "k_bracket", "k_main", "k_hist_a", "k_resolve", "k_finish", "k_fullscan", "k_gather_sample",
+TOPK = ("k_sample", "k_bracket", "k_main", "k_hist_a", "k_resolve", "k_finish", "k_fullscan", "k_gather_sample",  # (k_hist_a: rounds 2-4)
         "k_bracket_from_hist")
 
 

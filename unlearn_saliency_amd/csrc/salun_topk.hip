@@ -19,12 +19,14 @@
 //               k <= 0 / k >= n need no bracket (nothing / everything selected; k == n publishes the minimum)
 //   k_main      the one streaming pass: writes mask_j = [key > mid_j] (final outside the bracket), counts
 //               c_gt_j = #{key > hi_j}, compacts the in-bracket candidates (key, flat index) into per-workgroup slabs
-//               and leaves a 128-bin u16 histogram row of them per (workgroup, threshold); exact zeros are counted,
-//               never compacted (a real accumulator holds several per cent of them)
+//               (what a slab cannot take — a layer whose magnitudes sit at the threshold — goes to the threshold's
+//               shared spill row) and leaves a 128-bin u16 histogram row of them per (workgroup, threshold); exact
+//               zeros are counted, never compacted (a real accumulator holds several per cent of them)
 //   k_resolve   every workgroup sums the rows, picks the bin holding rank k_j - c_gt_j; candidates above it get their
 //               mask byte, candidates inside it go to a short list + a 4096-bin histogram of that bin
-//   k_finish    one workgroup per threshold: picks the final bin (<= a few keys wide), ranks its residents
-//               exactly (key descending, flat index ascending) and publishes tau_j
+//   k_finish    one workgroup per 64 short-list segments (<= 8 per threshold): picks the final bin (<= a few keys
+//               wide), settles its share of the list, hands the final bin's residents over write-through; the last
+//               ticket ranks them exactly (key descending, flat index ascending) and publishes tau_j
 //   A threshold that lands in the block of exact zeros (tau = |0|) is finished by the tie pass of the launch behind
 //   k_finish: per-chunk zero counts, a scan, and the first k_j - #{nonzero} zeros by flat index get their byte.
 //   For n >= 2^27 the bracket comes from an exact selection (this same route, values only) on a 2^20-element sample

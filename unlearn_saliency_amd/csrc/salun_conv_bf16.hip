@@ -96,6 +96,7 @@ struct IgArgs {
   int Kf, Cf;              // forward dims of the packed weights
   float *part;             // split reduction: fp32 partial tiles [split][M][Kout] (null when gridDim.z == 1)
   int stages_per_split;    // reduction stages (tap x channel chunk) per blockIdx.z
+  uint32_t x_bytes, w_bytes;  // extents of x and wp (buffer descriptors: reads past them return zeros)
 };
 
 template <int WM, int WN, int BK, bool BTR>
@@ -122,12 +123,17 @@ void conv_bf16_igemm(const IgArgs g) {
   const int st_begin = blockIdx.z * g.stages_per_split;
   const int st_end = min(nstage_all, st_begin + g.stages_per_split);
 
-  // ---- the A rows this thread stages (fixed for the kernel)
+  // ---- the A rows this thread stages (fixed for the kernel): CPR consecutive lanes share one row, so a quad of lanes
+  // loads one 64-byte line (dealing eight consecutive lanes to eight ROWS instead makes the ds_write_b128 of a stage
+  // conflict-free, but every lane quad then touches four lines: forward 545 -> 469 TFLOP/s over the SD layer table,
+  // measured on one box, profiles/r05_convbench_bf16_ab.txt)
+  constexpr int RPP = NTHR / CPR;             // rows per pass
   const int a_cc = tid % CPR;
+  const int a_row0 = tid / CPR;
   int a_hb[NA], a_wb[NA], a_nb[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = tid / CPR + (NTHR / CPR) * i;
+    const int row = a_row0 + RPP * i;
     const int m = m0 + row;
     if (m < g.M) {
       const int n = m / (g.OH * g.OW);
@@ -140,17 +146,22 @@ void conv_bf16_igemm(const IgArgs g) {
       a_hb[i] = -(1 << 20); a_wb[i] = 0; a_nb[i] = 0;  // never in range
     }
   }
-  // Staging is BRANCH FREE: every load is issued unconditionally from a clamped (always valid) address and zero-filled
-  // rows are masked when the registers are written to LDS.  With a branch around a load hipcc cannot count the loads in
-  // flight and waits `vmcnt(0)` before the LDS write — which would also drain the loads of the stage after next and
-  // collapse the two-deep register ring below to depth one (measured: the ring then changes nothing).
-  int wb_base[NB];  // per-thread constant part of the weight offsets (elements)
+  // Staging costs NO vector-ALU work per stage (round 5; it was ~50 instructions per stage and thread — 8 per MFMA —
+  // and the kernel's waves spent as many cycles in the vector ALU as in the matrix pipe): both operands come through
+  // buffer descriptors, address = descriptor base + per-lane VGPR offset + wave-uniform SGPR offset.  The per-lane part
+  // of an A row (pixel of this TAP, or an offset past the end of the buffer when the tap falls outside the image — the
+  // hardware then returns zeros: no masks, no branches) is recomputed once per tap; the channel chunk of a stage is the
+  // SGPR part.  The per-lane part of a weight row is a kernel constant, tap and channel chunk are the SGPR part.
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.x), 0, (int)g.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.wp), 0, (int)g.w_bytes, 0x00020000);
+  constexpr uint32_t OOB = 0x80000000u;  // past the end of x (launch_igemm refuses x >= 2^31 bytes)
+  uint32_t wvo[NB];  // per-thread constant byte offsets of the weight chunks
   if (!BTR) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int row = tid / CPR + (NTHR / CPR) * i;
+      const int row = a_row0 + RPP * i;
       const int k = min(n0 + row, g.Kout - 1);  // rows past the last channel re-read it: their results are never stored
-      wb_base[i] = k * RS * g.Cin + a_cc * 8;
+      wvo[i] = (uint32_t)(k * RS * g.Cin + a_cc * 8) * 2u;
     }
   } else {
     constexpr int CPB = BN / 8;
@@ -158,14 +169,12 @@ void conv_bf16_igemm(const IgArgs g) {
     for (int i = 0; i < NB; ++i) {
       const int id = tid + NTHR * i;
       const int row = id / CPB, cc = id - row * CPB;
-      wb_base[i] = row * RS * g.Cf + min(n0 + cc * 8, g.Kout - 8);
+      wvo[i] = (uint32_t)(row * RS * g.Cf + min(n0 + cc * 8, g.Kout - 8)) * 2u;
     }
   }
-  uint4 r0[NA + NB], r1[NA + NB], r2[NA + NB];  // one register set = the A chunks followed by the B chunks of a stage
-  uint32_t ma0[NA], ma1[NA], ma2[NA];
-  auto load_stage = [&](int st, uint4 (&rr)[NA + NB], uint32_t (&ma)[NA]) {
-    const int tap = st / cchunks, c0 = (st - tap * cchunks) * BK;
-    const int r = tap / g.R, s = tap - r * g.R;
+  uint32_t avo[NA];  // byte offsets of this thread's A chunks for the tap being loaded (OOB: outside the image)
+  auto aim_tap = [&](int tap) {
+    const int r = (g.R == 3) ? (tap * 11) >> 5 : 0, s = tap - r * g.R;  // tap / 3 for tap < 9
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int vh = a_hb[i] + r, vw = a_wb[i] + s;
@@ -173,25 +182,49 @@ void conv_bf16_igemm(const IgArgs g) {
       if (g.up == 2) { ok = !((vh | vw) & 1); vh >>= 1; vw >>= 1; }
       ok = ok && vh >= 0 && vh < g.H && vw >= 0 && vw < g.W;
       const uint32_t pix = (uint32_t)(a_nb[i] + __mul24(vh, g.W) + vw);        // < 2^24 pixels
-      const uint32_t off = ok ? __umul24(pix, (uint32_t)g.Cin) + (uint32_t)(c0 + a_cc * 8) : 0u;
-      ma[i] = ok ? 0xffffffffu : 0u;
-      rr[i] = *reinterpret_cast<const uint4 *>(g.x + off);
+      avo[i] = ok ? (__umul24(pix, (uint32_t)g.Cin) + (uint32_t)(a_cc * 8)) * 2u : OOB;
     }
-    const int wu = BTR ? (c0 * RS + (RS - 1 - tap)) * g.Cf : tap * g.Cin + c0;  // wave-uniform part
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rr[NA + i] = *reinterpret_cast<const uint4 *>(g.wp + (uint32_t)(wb_base[i] + wu));
   };
-  auto store_stage = [&](int buf, const uint4 (&rr)[NA + NB], const uint32_t (&ma)[NA]) {
+  // wave-uniform state of the LOAD side: next stage to fetch, its tap and first channel
+  const int last = st_end - 1;
+  int ls = st_begin, ltap = st_begin / cchunks, lc0 = (st_begin - ltap * cchunks) * BK;
+  bool lneed = true;
+  uint32_t wu_prev = 0;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  auto ld128 = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, uint32_t soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  uint4 r0[NA + NB], r1[NA + NB], r2[NA + NB];  // one register set = the A chunks followed by the B chunks of a stage
+  // Loads stage `ls` into `rr`.  A stage index past the end (the loop takes stages three at a time) loads zeros for A
+  // (out-of-range offsets) and re-reads the last stage's weights: idle multiplies instead of branches in the loop.
+  auto issue = [&](uint4 (&rr)[NA + NB]) {
+    const bool dead = ls > last;  // uniform
+    if (!dead && lneed) { aim_tap(ltap); lneed = false; }
+    const uint32_t sa = (uint32_t)lc0 * 2u;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rr[i] = ld128(rx, dead ? OOB : avo[i], dead ? 0u : sa);
+    uint32_t wu = wu_prev;
+    if (!dead) wu = (uint32_t)(BTR ? (lc0 * RS + (RS - 1 - ltap)) * g.Cf : ltap * g.Cin + lc0) * 2u;
+    wu_prev = wu;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rr[NA + i] = ld128(rw, wvo[i], wu);
+    ++ls;
+    if (!dead) {
+      lc0 += BK;
+      if (lc0 == g.Cin) { lc0 = 0; ++ltap; lneed = true; }
+    }
+  };
+  auto store_stage = [&](int buf, const uint4 (&rr)[NA + NB]) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int row = tid / CPR + (NTHR / CPR) * i;
-      *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + row * ROWB + a_cc * 16) =
-          make_uint4(rr[i].x & ma[i], rr[i].y & ma[i], rr[i].z & ma[i], rr[i].w & ma[i]);
+      const int row = a_row0 + RPP * i;
+      *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + row * ROWB + a_cc * 16) = rr[i];
     }
     if (!BTR) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int row = tid / CPR + (NTHR / CPR) * i;
+        const int row = a_row0 + RPP * i;
         *reinterpret_cast<uint4 *>(lds + buf * STAGE_BYTES + A_BYTES + row * ROWB + a_cc * 16) = rr[NA + i];
       }
     } else {
@@ -242,37 +275,28 @@ void conv_bf16_igemm(const IgArgs g) {
   // Two-deep register ring over a double-buffered LDS tile: while stage s is multiplied, stage s+1 sits in registers
   // (written to the other LDS buffer after the MFMAs) and the loads of stage s+2 are issued into the set stage s left.
   // Stages are taken three at a time (static register naming, three register sets: the loads of stages s+1 .. s+3 are
-  // in flight while stage s is multiplied); a stage index past the end re-loads the last stage with its A rows masked to
-  // zero, so a count that is not a multiple of three costs idle multiplies instead of branches inside the loop (a
-  // wave-uniform skip of those multiplies was tried: it cost backward-data its register budget, 2.07 -> 3.04 ms).
-  const int last = st_end - 1;
-#define SALUN_IG_LOAD(S, R, M)                       \
-  load_stage(min((S), last), R, M);                  \
-  if ((S) > last) {                                  \
-    _Pragma("unroll") for (int i = 0; i < NA; ++i) M[i] = 0u; \
-  }
-  SALUN_IG_LOAD(st_begin, r0, ma0)
-  SALUN_IG_LOAD(st_begin + 1, r1, ma1)
-  SALUN_IG_LOAD(st_begin + 2, r2, ma2)
-  store_stage(0, r0, ma0);
+  // in flight while stage s is multiplied).
+  issue(r0);
+  issue(r1);
+  issue(r2);
+  store_stage(0, r0);
   __syncthreads();
   int buf = 0;
   for (int st = st_begin; st < st_end; st += 3) {
-    SALUN_IG_LOAD(st + 3, r0, ma0)
+    issue(r0);
     compute(buf);
-    store_stage(buf ^ 1, r1, ma1);
+    store_stage(buf ^ 1, r1);
     __syncthreads();
-    SALUN_IG_LOAD(st + 4, r1, ma1)
+    issue(r1);
     compute(buf ^ 1);
-    store_stage(buf, r2, ma2);
+    store_stage(buf, r2);
     __syncthreads();
-    SALUN_IG_LOAD(st + 5, r2, ma2)
+    issue(r2);
     compute(buf);
-    store_stage(buf ^ 1, r0, ma0);
+    store_stage(buf ^ 1, r0);
     __syncthreads();
     buf ^= 1;
   }
-#undef SALUN_IG_LOAD
   if (g.part) {  // split reduction: raw fp32 tile, finished by k_splitk_finish
     float *dst = g.part + (size_t)blockIdx.z * g.M * g.Kout;
 #pragma unroll
@@ -359,6 +383,7 @@ struct WgArgs {
   int N, H, W, C, OH, OW, K, pad;
   int tiles_h, tiles_w;       // 8x8 output-pixel chunks per image
   int chunks, per_split;      // total chunks, chunks per split
+  uint32_t x_bytes, dy_bytes; // extents of x and dy (buffer descriptors: reads past them return zeros)
 };
 
 // R: filter size (1 or 3); ST: convolution stride (1 or 2).  Workgroup tile = 64 k x 64 c x all R*R taps; wave (wk, wc)
@@ -382,47 +407,87 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
   const int cb = split * g.per_split;
   const int ce = min(g.chunks, cb + g.per_split);
 
-  uint4 rdy[NDY], rx[NX];
-  auto load_stage = [&](int chunk) {
+  // Staging (round 5).  With 144 accumulator registers the kernel runs ONE wave per SIMD, and 36 bf16 MFMAs per chunk are
+  // ~1,150 cycles — less than a trip to HBM — so a single chunk of prefetch left the matrix pipe waiting on loads.  Now
+  // three register sets ring over the double-buffered LDS tile (the loads of chunks s+1 .. s+3 are in flight while chunk
+  // s is multiplied), and every load goes through a buffer descriptor: a lane whose pixel / channel lies outside the
+  // tensor reads at an offset past its end and gets zeros — no branch around a load (hipcc cannot count loads behind a
+  // branch and would wait for ALL of them before the first LDS store), no masks.
+  const __amdgpu_buffer_rsrc_t rdyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.dy), 0, (int)g.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.x), 0, (int)g.x_bytes, 0x00020000);
+  constexpr uint32_t OOB = 0x80000000u;  // past the end of either tensor (the launcher refuses >= 2^31 bytes)
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  auto ld128 = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, uint32_t soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  // per-thread constants of the items it stages
+  int dy_row[NDY], dy_col[NDY];
+  uint32_t dy_vo[NDY];   // byte offset inside the 8x8 tile (OOB: channel past K)
+#pragma unroll
+  for (int i = 0; i < NDY; ++i) {
+    const int id = tid + 256 * i;
+    const int px = id >> 3, cc = id & 7;
+    dy_row[i] = px >> 3; dy_col[i] = px & 7;
+    const int k = k0 + cc * 8;
+    dy_vo[i] = (k < g.K) ? (uint32_t)(((px >> 3) * g.OW + (px & 7)) * g.K + k) * 2u : OOB;
+  }
+  int x_row[NX], x_col[NX], x_vo[NX];  // patch position and byte offset relative to the patch origin; row < -2^20: never valid
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int id = tid + 256 * i;
+    const int px = id >> 3, cc = id & 7;
+    const int c = c0 + cc * 8;
+    const bool live = px < PPX && c < g.C;
+    x_row[i] = live ? px / PW : -(1 << 24);
+    x_col[i] = px % PW;
+    x_vo[i] = ((px / PW) * g.W + (px % PW)) * g.C * 2 + c * 2;
+  }
+  // wave-uniform state of the LOAD side: next chunk to fetch = (image ln, tile row lth, tile column ltw)
+  int lch = cb;
+  int ln, lth, ltw;
+  {
     const int per_img = g.tiles_h * g.tiles_w;
-    const int n = chunk / per_img;
-    const int t = chunk - n * per_img;
-    const int oh0 = (t / g.tiles_w) * 8, ow0 = (t % g.tiles_w) * 8;
+    ln = cb / per_img;
+    const int t = cb - ln * per_img;
+    lth = t / g.tiles_w; ltw = t - lth * g.tiles_w;
+  }
+  uint4 s0[NDY + NX], s1[NDY + NX], s2[NDY + NX];
+  auto issue = [&](uint4 (&rr)[NDY + NX]) {
+    const bool dead = lch >= ce;  // uniform: nothing left to fetch (the register set is not used afterwards)
+    if (!dead) {
+      const int oh0 = lth * 8, ow0 = ltw * 8;
+      const uint32_t dsoff = (uint32_t)(((ln * g.OH + oh0) * g.OW + ow0) * g.K) * 2u;
 #pragma unroll
-    for (int i = 0; i < NDY; ++i) {
-      const int id = tid + 256 * i;
-      const int px = id >> 3, cc = id & 7;
-      const int oh = oh0 + (px >> 3), ow = ow0 + (px & 7);
-      const int k = k0 + cc * 8;
-      rdy[i] = make_uint4(0, 0, 0, 0);
-      if (oh < g.OH && ow < g.OW && k < g.K)
-        rdy[i] = *reinterpret_cast<const uint4 *>(g.dy + ((size_t)((n * g.OH + oh) * g.OW + ow) * g.K + k));
-    }
-    const int ih0 = oh0 * ST - g.pad, iw0 = ow0 * ST - g.pad;
+      for (int i = 0; i < NDY; ++i) {
+        const bool ok = (oh0 + dy_row[i] < g.OH) && (ow0 + dy_col[i] < g.OW);
+        rr[i] = ld128(rdyb, ok ? dy_vo[i] : OOB, dsoff);
+      }
+      const int ih0 = oh0 * ST - g.pad, iw0 = ow0 * ST - g.pad;
+      const int xbase = ((ln * g.H + ih0) * g.W + iw0) * g.C * 2;  // may be negative (first rows of the first image)
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int id = tid + 256 * i;
-      const int px = id >> 3, cc = id & 7;
-      const int ih = ih0 + px / PW, iw = iw0 + px % PW;
-      const int c = c0 + cc * 8;
-      rx[i] = make_uint4(0, 0, 0, 0);
-      if (px < PPX && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && c < g.C)
-        rx[i] = *reinterpret_cast<const uint4 *>(g.x + ((size_t)((n * g.H + ih) * g.W + iw) * g.C + c));
+      for (int i = 0; i < NX; ++i) {
+        const int ih = ih0 + x_row[i], iw = iw0 + x_col[i];
+        const bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+        rr[NDY + i] = ld128(rxb, ok ? (uint32_t)(xbase + x_vo[i]) : OOB, 0u);
+      }
+      ++lch;
+      if (++ltw == g.tiles_w) { ltw = 0; if (++lth == g.tiles_h) { lth = 0; ++ln; } }
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, const uint4 (&rr)[NDY + NX]) {
     char *base = lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NDY; ++i) {
       const int id = tid + 256 * i;
       const int px = id >> 3, cc = id & 7;
-      *reinterpret_cast<uint4 *>(base + (cc >> 2) * DY_BLK + px * 64 + (cc & 3) * 16) = rdy[i];
+      *reinterpret_cast<uint4 *>(base + (cc >> 2) * DY_BLK + px * 64 + (cc & 3) * 16) = rr[i];
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int id = tid + 256 * i;
       const int px = id >> 3, cc = id & 7;
-      if (px < PPX) *reinterpret_cast<uint4 *>(base + 2 * DY_BLK + (cc >> 2) * X_BLK + px * 64 + (cc & 3) * 16) = rx[i];
+      if (px < PPX) *reinterpret_cast<uint4 *>(base + 2 * DY_BLK + (cc >> 2) * X_BLK + px * 64 + (cc & 3) * 16) = rr[NDY + i];
     }
   };
 
@@ -439,15 +504,7 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
   // row 2*kk + (gq>>1), column (s>>2) and (s>>2)+4
   const uint32_t dy_off = (uint32_t)(wk * DY_BLK + (8 * (gq >> 1) + (sl >> 2)) * 64 + chan_b);
   const uint32_t x_off = (uint32_t)(2 * DY_BLK + wc * X_BLK + (((gq >> 1) * ST) * PW + (sl >> 2) * ST) * 64 + chan_b);
-
-  if (cb < ce) {
-    load_stage(cb);
-    store_stage(0);
-  }
-  __syncthreads();
-  for (int ch = cb; ch < ce; ++ch) {
-    const int buf = (ch - cb) & 1;
-    if (ch + 1 < ce) load_stage(ch + 1);
+  auto compute = [&](int buf) {
     const char *base = lds + buf * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -459,8 +516,34 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
       }
     }
-    if (ch + 1 < ce) store_stage(buf ^ 1);
+  };
+
+  // At the top of a trip chunk ch sits in LDS[buf], set s1 holds chunk ch + 1, s2 holds ch + 2 and s0 is free; the
+  // trip multiplies three chunks and refills the three sets (static register naming), the LDS buffers alternate.
+  issue(s0);
+  issue(s1);
+  issue(s2);
+  if (cb < ce) store_stage(0, s0);
+  __syncthreads();
+  int buf = 0;
+  for (int ch = cb; ch < ce; ch += 3) {
+    issue(s0);                                        // chunk ch + 3
+    compute(buf);                                     // chunk ch
+    if (ch + 1 < ce) store_stage(buf ^ 1, s1);
     __syncthreads();
+    if (ch + 1 < ce) {
+      issue(s1);                                      // chunk ch + 4
+      compute(buf ^ 1);                               // chunk ch + 1
+      if (ch + 2 < ce) store_stage(buf, s2);
+    }
+    __syncthreads();
+    if (ch + 2 < ce) {
+      issue(s2);                                      // chunk ch + 5
+      compute(buf);                                   // chunk ch + 2
+      if (ch + 3 < ce) store_stage(buf ^ 1, s0);
+    }
+    __syncthreads();
+    buf ^= 1;
   }
 
   // ---- partials: part[split][tap][k][c]; D row = k, col = c
@@ -607,6 +690,13 @@ int launch_igemm(IgArgs a, void *ws, size_t ws_bytes, hipStream_t st) {
   if (sp.splits > 1 && (!ws || ws_bytes < (size_t)sp.splits * a.M * a.Kout * sizeof(float))) sp = {1, nstage};
   a.stages_per_split = sp.per;
   a.part = sp.splits > 1 ? static_cast<float *>(ws) : nullptr;
+  {  // buffer descriptors: an out-of-image tap reads at byte offset 2^31, which must lie past the end of x
+    const size_t xb = (size_t)(a.M / (a.OH * a.OW)) * a.H * a.W * a.Cin * 2;  // N images of H x W x Cin bf16
+    const size_t wb = (size_t)a.Kf * a.R * a.R * a.Cf * 2;
+    if (xb >= ((size_t)1 << 31) || wb >= ((size_t)1 << 32)) return SALUN_EINVAL;
+    a.x_bytes = (uint32_t)xb;
+    a.w_bytes = (uint32_t)wb;
+  }
   hipLaunchKernelGGL((conv_bf16_igemm<WM, WN, BK, BTR>), dim3(mt, nt, sp.splits), dim3(64 * WM * WN), lds, st, a);
   SALUN_LAUNCH_CHECK();
   if (sp.splits > 1) {
@@ -644,8 +734,15 @@ int launch_wgrad(const WgArgs &a, int splits, hipStream_t st) {
       return SALUN_EIO;
     attr_done |= 1ull << salun_device_bit();
   }
+  WgArgs b = a;
+  {  // buffer descriptors: an out-of-image lane reads at byte offset 2^31, which must lie past the end of both tensors
+    const size_t xb = (size_t)a.N * a.H * a.W * a.C * 2, db = (size_t)a.N * a.OH * a.OW * a.K * 2;
+    if (xb >= ((size_t)1 << 31) || db >= ((size_t)1 << 31)) return SALUN_EINVAL;
+    b.x_bytes = (uint32_t)xb;
+    b.dy_bytes = (uint32_t)db;
+  }
   dim3 grid((a.K + 63) / 64, (a.C + 63) / 64, splits);
-  hipLaunchKernelGGL((conv_bf16_wgrad<R, ST>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_bf16_wgrad<R, ST>), grid, dim3(256), lds, st, b);
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }
@@ -711,7 +808,7 @@ SALUN_EXPORT int salun_conv2d_bf16_forward(const uint16_t *x, const uint16_t *wp
                                                   salun_hip_stream(stream));
     if (rc != 0) return rc < 0 ? rc : SALUN_OK;
   }
-  IgArgs a{x, wp, bias, nbias, addend, y, N * OH * OW, H, W, C, OH, OW, K, R, stride, pad, 1, K, C, nullptr, 0};
+  IgArgs a{x, wp, bias, nbias, addend, y, N * OH * OW, H, W, C, OH, OW, K, R, stride, pad, 1, K, C, nullptr, 0, 0u, 0u};
   return dispatch_igemm<false>(a, ws, ws_bytes, salun_hip_stream(stream));
 }
 
@@ -727,7 +824,7 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_data(const uint16_t *dy, const uint1
   // the staging addresses use 24-bit multiplies: pixel counts and channel counts below 2^24
   if ((int64_t)N * H * W >= (1 << 24) || (int64_t)N * OH * OW >= (1 << 24) || C >= (1 << 24) || K >= (1 << 24)) return SALUN_EINVAL;
   // walk dX's pixels; the source is dY (zero-upsampled by `stride`), padding R-1-pad, taps flipped in the weight read
-  IgArgs a{dy, wp, nullptr, nullptr, addend, dx, N * H * W, OH, OW, K, H, W, C, R, 1, R - 1 - pad, stride, K, C, nullptr, 0};
+  IgArgs a{dy, wp, nullptr, nullptr, addend, dx, N * H * W, OH, OW, K, H, W, C, R, 1, R - 1 - pad, stride, K, C, nullptr, 0, 0u, 0u};
   return dispatch_igemm<true>(a, ws, ws_bytes, salun_hip_stream(stream));
 }
 

@@ -389,8 +389,18 @@ struct WgArgs {
 // R: filter size (1 or 3); ST: convolution stride (1 or 2).  Workgroup tile = 64 k x 64 c x all R*R taps; wave (wk, wc)
 // owns 32 k x 32 c.  One stage = one 8x8 block of output pixels: dY rows [64 px][64 k] and the input patch
 // [(7*ST+R)^2 px][64 c], both as two [px][32 ch] column blocks with 64-byte rows.
+//
+// Two shapes of the same loop.  The 3x3 stride-1 kernel keeps its 144 accumulators + ONE staging register set inside 256
+// registers (233) and 42 KB of LDS, so TWO workgroups share a CU and each hides the other's loads: 2.40 -> 2.05 ms over
+// the SD layer table against one workgroup per CU with a ring of three register sets (same box, alternated,
+// profiles/r05_convbench_bf16_ab.txt).  The stride-2 kernel stages a 17x17 patch (90 KB double buffered): two
+// workgroups do not fit a CU's LDS, the single set then loses 7 - 10 %, so it (and the 1x1 fallback) keeps the ring.
+#ifndef SALUN_BF16_WGRAD_EXP
+#define SALUN_BF16_WGRAD_EXP 0  // timing experiments only (profiles/r05_wgrad_phases.txt): 1 = no stores, 2 = no reduction
+#endif
 template <int R, int ST>
-__global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
+__global__ __launch_bounds__(256, (R == 3 && ST == 1) ? 2 : 1) void conv_bf16_wgrad(const WgArgs g) {
+  constexpr bool PAIRED = R == 3 && ST == 1;   // two workgroups per CU, one register set
   constexpr int RS = R * R;
   constexpr int PW = 7 * ST + R;               // patch width = height
   constexpr int PPX = PW * PW;
@@ -405,12 +415,16 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
   const int wk = wave & 1, wc = wave >> 1;
   const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, split = blockIdx.z;
   const int cb = split * g.per_split;
+#if SALUN_BF16_WGRAD_EXP == 2
+  const int ce = cb;  // timing experiment: no reduction at all, the epilogue alone
+#else
   const int ce = min(g.chunks, cb + g.per_split);
+#endif
 
-  // Staging (round 5).  With 144 accumulator registers the kernel runs ONE wave per SIMD, and 36 bf16 MFMAs per chunk are
-  // ~1,150 cycles — less than a trip to HBM — so a single chunk of prefetch left the matrix pipe waiting on loads.  Now
-  // three register sets ring over the double-buffered LDS tile (the loads of chunks s+1 .. s+3 are in flight while chunk
-  // s is multiplied), and every load goes through a buffer descriptor: a lane whose pixel / channel lies outside the
+  // Staging (round 5).  36 bf16 MFMAs per chunk are ~1,150 cycles — less than a trip to HBM — so ONE wave per SIMD with a
+  // single chunk of prefetch left the matrix pipe waiting on loads.  The ring variant keeps three register sets over the
+  // double-buffered LDS tile (the loads of chunks s+1 .. s+3 are in flight while chunk s is multiplied); the paired
+  // variant has a second workgroup on the CU instead.  Every load goes through a buffer descriptor: a lane whose pixel / channel lies outside the
   // tensor reads at an offset past its end and gets zeros — no branch around a load (hipcc cannot count loads behind a
   // branch and would wait for ALL of them before the first LDS store), no masks.
   const __amdgpu_buffer_rsrc_t rdyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(g.dy), 0, (int)g.dy_bytes, 0x00020000);
@@ -518,39 +532,55 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
     }
   };
 
-  // At the top of a trip chunk ch sits in LDS[buf], set s1 holds chunk ch + 1, s2 holds ch + 2 and s0 is free; the
-  // trip multiplies three chunks and refills the three sets (static register naming), the LDS buffers alternate.
-  issue(s0);
-  issue(s1);
-  issue(s2);
-  if (cb < ce) store_stage(0, s0);
-  __syncthreads();
-  int buf = 0;
-  for (int ch = cb; ch < ce; ch += 3) {
-    issue(s0);                                        // chunk ch + 3
-    compute(buf);                                     // chunk ch
-    if (ch + 1 < ce) store_stage(buf ^ 1, s1);
+  if constexpr (PAIRED) {
+    // one set: chunk ch + 1 is in flight while chunk ch is multiplied; the other workgroup on the CU covers the rest
+    issue(s0);
+    if (cb < ce) store_stage(0, s0);
     __syncthreads();
-    if (ch + 1 < ce) {
-      issue(s1);                                      // chunk ch + 4
-      compute(buf ^ 1);                               // chunk ch + 1
-      if (ch + 2 < ce) store_stage(buf, s2);
+    for (int ch = cb; ch < ce; ++ch) {
+      const int b1 = (ch - cb) & 1;
+      issue(s0);                                        // chunk ch + 1
+      compute(b1);                                      // chunk ch
+      if (ch + 1 < ce) store_stage(b1 ^ 1, s0);
+      __syncthreads();
     }
+  } else {
+    // At the top of a trip chunk ch sits in LDS[buf], set s1 holds chunk ch + 1, s2 holds ch + 2 and s0 is free; the
+    // trip multiplies three chunks and refills the three sets (static register naming), the LDS buffers alternate.
+    issue(s0);
+    issue(s1);
+    issue(s2);
+    if (cb < ce) store_stage(0, s0);
     __syncthreads();
-    if (ch + 2 < ce) {
-      issue(s2);                                      // chunk ch + 5
-      compute(buf);                                   // chunk ch + 2
-      if (ch + 3 < ce) store_stage(buf ^ 1, s0);
+    int buf = 0;
+    for (int ch = cb; ch < ce; ch += 3) {
+      issue(s0);                                        // chunk ch + 3
+      compute(buf);                                     // chunk ch
+      if (ch + 1 < ce) store_stage(buf ^ 1, s1);
+      __syncthreads();
+      if (ch + 1 < ce) {
+        issue(s1);                                      // chunk ch + 4
+        compute(buf ^ 1);                               // chunk ch + 1
+        if (ch + 2 < ce) store_stage(buf, s2);
+      }
+      __syncthreads();
+      if (ch + 2 < ce) {
+        issue(s2);                                      // chunk ch + 5
+        compute(buf);                                   // chunk ch + 2
+        if (ch + 3 < ce) store_stage(buf ^ 1, s0);
+      }
+      __syncthreads();
+      buf ^= 1;
     }
-    __syncthreads();
-    buf ^= 1;
   }
 
   // ---- partials: part[split][tap][k][c]; D row = k, col = c
   const int c = c0 + wc * 32 + (lane & 31);
   if (g.direct) {
     // one split: this workgroup holds the whole sum of its (k, c) tile — a lane owns all R*R taps of an element, i.e.
-    // R*R consecutive floats of the OIHW gradient, and the 32 lanes of a row 32*R*R consecutive floats
+    // R*R consecutive floats of the OIHW gradient, and the 32 lanes of a row 32*R*R consecutive floats.  (Sending the
+    // tile through LDS to store whole rows was measured in round 5: 8x8 layers 67 -> 64 us, 16x16 layers +1 .. +6 us,
+    // the stride-2 kernel 92 -> 115 us, the SD step +1 % — the L2 merges the nine partial stores of a line; not kept.)
     if (c < g.C) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
@@ -558,7 +588,12 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
         if (k < g.K) {
           float *dst = g.dw + ((size_t)k * g.C + c) * RS;
 #pragma unroll
-          for (int t = 0; t < RS; ++t) dst[t] = g.accumulate ? dst[t] + acc[t][v] : acc[t][v];
+          for (int t = 0; t < RS; ++t) {
+#if SALUN_BF16_WGRAD_EXP == 1
+            if (acc[t][v] != 12345.678f) continue;
+#endif
+            dst[t] = g.accumulate ? dst[t] + acc[t][v] : acc[t][v];
+          }
         }
       }
     }
@@ -571,24 +606,37 @@ __global__ __launch_bounds__(256) void conv_bf16_wgrad(const WgArgs g) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int k = k0 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+#if SALUN_BF16_WGRAD_EXP == 1
+        if (acc[t][v] != 12345.678f) continue;
+#endif
         if (k < g.K) dst[(size_t)k * g.C + c] = acc[t][v];
       }
     }
   }
 }
 
-// part[split][RS][K][C] -> dw[K][C][RS] (OIHW), summed over splits in index order; thread = one (k, c), all taps
+// part[split][RS][K][C] -> dw[K][C][RS] (OIHW), summed over splits in index order.  Block = 64 consecutive (k, c) pairs:
+// thread (q, j) sums taps q, q + 4, q + 8 of pair j (reads coalesced over j, four times the workgroups of a thread per
+// pair), and the 64 * RS sums leave through LDS as the 64 * RS CONSECUTIVE floats they are in dw.
 __global__ __launch_bounds__(256) void k_wgrad_reduce_bf16(const float *__restrict__ part, float *__restrict__ dw, int K,
                                                            int C, int RS, int splits, int accumulate) {
+  __shared__ float sm[64 * 9];
   const int64_t kc = (int64_t)K * C;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= kc) return;
-  for (int t = 0; t < RS; ++t) {
-    float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += part[((int64_t)sp * RS + t) * kc + i];
-    float *d = dw + i * RS + t;
-    *d = accumulate ? (*d + s) : s;
-  }
+  const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * 64, i = i0 + j;
+  if (i < kc)
+    for (int t = q; t < RS; t += 4) {
+      float s = 0.f;
+      for (int sp = 0; sp < splits; ++sp) s += part[((int64_t)sp * RS + t) * kc + i];
+      sm[j * RS + t] = s;
+    }
+  __syncthreads();
+  const int64_t o0 = i0 * RS, total = kc * RS;
+  for (int idx = threadIdx.x; idx < 64 * RS; idx += 256)
+    if (o0 + idx < total) {
+      float *d = dw + o0 + idx;
+      *d = accumulate ? (*d + sm[idx]) : sm[idx];
+    }
 }
 
 // per-channel sum over pixels of an NHWC bf16 tensor (the bias gradient): [M][K] -> fp32 [K], two deterministic stages.
@@ -638,12 +686,18 @@ __global__ __launch_bounds__(256) void k_colsum_finish(const float *__restrict__
   }
 }
 
+#ifndef SALUN_BF16_WGRAD_TARGET
+#define SALUN_BF16_WGRAD_TARGET 384
+#endif
+#ifndef SALUN_BF16_WGRAD_FLOOR
+#define SALUN_BF16_WGRAD_FLOOR 0
+#endif
 int wgrad_splits(int tiles, int chunks) {
   // about 1.5 workgroups per CU, never more splits than chunks
   // measured on the SD-v1 step (round 3, one box, four builds): 1536 / 768 / 384 / 256 target workgroups ->
   // 219.3 / 209.3 / 205.7 / 206.6 ms — every split adds a K*C*R*R fp32 partial to write and re-read (59 MB for a
   // 1280x1280 3x3 layer), which costs more than the second resident round of workgroups gives back
-  int s = (384 + tiles - 1) / tiles;
+  int s = SALUN_BF16_WGRAD_FLOOR ? SALUN_BF16_WGRAD_TARGET / tiles : (SALUN_BF16_WGRAD_TARGET + tiles - 1) / tiles;
   if (s > chunks) s = chunks;
   if (s > 64) s = 64;
   if (s < 1) s = 1;
@@ -905,7 +959,7 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
   if (rc != SALUN_OK) return rc;
   if (!a.direct) {
     const int64_t kc = (int64_t)K * C;
-    hipLaunchKernelGGL(k_wgrad_reduce_bf16, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, st, a.part, dw, K, C, R * R,
+    hipLaunchKernelGGL(k_wgrad_reduce_bf16, dim3((unsigned)((kc + 63) / 64)), dim3(256), 0, st, a.part, dw, K, C, R * R,
                        splits, accumulate);
     SALUN_LAUNCH_CHECK();
   }

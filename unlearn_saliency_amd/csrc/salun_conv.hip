@@ -341,29 +341,54 @@ __global__ __launch_bounds__(256, FAST ? SALUN_IGEMM_OCC : 1) void conv_igemm(co
 
   // ---- epilogue: D[row = channel][col = pixel]; row = (v&3) + 8*(v>>2) + 4*hi
   if ((SALUN_IGEMM_EXP & 8) && N > 0) return;
+  // The epilogue terms of a 32-channel tile are ALL read before its first store (round 5).  Written element by element
+  // (`o += bias[k]; o += addend[oi]; y[oi] = o`) every load sat behind the previous element's store — y may alias the
+  // addend, so the compiler keeps the order — and waited for alone: up to 3 x 64 serial trips to memory per lane at
+  // the end of the two busiest kernels of the DDPM step.
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int n_out = n0 + ni_l[pt], p_out = p0 + p_l[pt];
     if (n_out < N) {
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
-        const int kbase = k0 + (wk * KT + t) * 32;
+        const int kbase = k0 + (wk * KT + t) * 32 + 4 * hi;
+        const size_t obase = (((size_t)n_out * yC + kbase) * P + p_out) * Q + q_l[pt];
+        const size_t kstride = (size_t)P * Q;
+        // loads are unconditional (a row past the last channel re-reads the last one): a load behind a per-lane test
+        // becomes a branch with its own wait
+        float bv[16], nv[16], av[16];
+        const int klast = yC - 1 - kbase;  // < 0: the whole tile is past the last channel (nothing is stored)
+        if (bias) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int kr = max(min((v & 3) + 8 * (v >> 2), klast), -kbase);
+            bv[v] = DGRAD ? bias[obase + (long long)kr * (long long)kstride] : bias[kbase + kr];  // backward-data: `bias` is a full-size addend (may alias y)
+          }
+        }
+        if (EPI && nbias) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) nv[v] = nbias[(size_t)n_out * yC + kbase + max(min((v & 3) + 8 * (v >> 2), klast), -kbase)];
+        }
+        if (EPI && addend) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            av[v] = addend[obase + (long long)max(min((v & 3) + 8 * (v >> 2), klast), -kbase) * (long long)kstride];
+        }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
-          if (k < yC) {
+          const int kr = (v & 3) + 8 * (v >> 2);
+          if (kbase + kr < yC) {
             float o = acc[pt][t][v];
-            const size_t oi = (((size_t)n_out * yC + k) * P + p_out) * Q + q_l[pt];
-            if (bias) o += DGRAD ? bias[oi] : bias[k];  // backward-data: `bias` is a full-size addend (may alias y)
+            if (bias) o += bv[v];
             if (EPI) {
               // forward, EPI instantiations only (a template parameter: as run-time branches these two tests cost the
               // plain instantiations 0.5 % of the ResNet-18 step): the per-image channel bias (the time/class embedding
               // projection of a diffusion ResnetBlock), then a full-size addend (the block's skip branch) — the order
               // the reference's separate adds produce (DDPM/models/diffusion.py:113-127)
-              if (nbias) o += nbias[(size_t)n_out * yC + k];
-              if (addend) o += addend[oi];
+              if (nbias) o += nv[v];
+              if (addend) o += av[v];
             }
-            y[oi] = o;
+            y[obase + kr * kstride] = o;
           }
         }
       }
@@ -559,15 +584,25 @@ __global__ __launch_bounds__(256) void conv_igemm_tap(const IgemmArgs g) {
   if (n_out < g.N) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      const int kbase = k0 + (wk * KT + t) * 32;
+      const int kbase = k0 + (wk * KT + t) * 32 + 4 * hi;
+      const size_t obase = (((size_t)n_out * g.yC + kbase) * g.yH + h_out) * g.yW + w_out;
+      const size_t kstride = (size_t)g.yH * g.yW;
+      float bv[16];  // all epilogue terms of the tile are read before its first store, unconditionally (see conv_igemm)
+      const int klast = g.yC - 1 - kbase;
+      if (g.bias) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int kr = max(min((v & 3) + 8 * (v >> 2), klast), -kbase);
+          bv[v] = DGRAD ? g.bias[obase + (long long)kr * (long long)kstride] : g.bias[kbase + kr];
+        }
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int k = kbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
-        if (k < g.yC) {
+        const int kr = (v & 3) + 8 * (v >> 2);
+        if (kbase + kr < g.yC) {
           float o = acc[t][v];
-          const size_t oi = (((size_t)n_out * g.yC + k) * g.yH + h_out) * g.yW + w_out;
-          if (g.bias) o += DGRAD ? g.bias[oi] : g.bias[k];
-          g.y[oi] = o;
+          if (g.bias) o += bv[v];
+          g.y[obase + kr * kstride] = o;
         }
       }
     }
@@ -740,28 +775,42 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2(const float *__restrict_
   if (n_out < N) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      const int cbase = c0out + (wk * KT + t) * 32;
+      const int cbase = c0out + (wk * KT + t) * 32 + 4 * hi;
+      const size_t obase = (((size_t)n_out * C + cbase) * H + 2 * a_out) * W + 2 * q_l;
+      const size_t cstride = (size_t)H * W;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int c = cbase + (v & 3) + 8 * (v >> 2) + 4 * hi;
-        if (c < C) {
+      for (int vb = 0; vb < 16; vb += 8) {
+        float2 ad[8][2];  // the addend of half a tile is read before its first store, unconditionally (see conv_igemm)
+        const int clast = C - 1 - cbase;
+        if (addend) {
 #pragma unroll
-          for (int ph = 0; ph < 2; ++ph) {
-            const size_t oi = (((size_t)n_out * C + c) * H + (2 * a_out + ph)) * W + 2 * q_l;
-            float2 o;
-            if (R == 1) {
-              o.x = (ph == 0) ? acc[0][t][v] : 0.f;
-              o.y = 0.f;
-            } else {
-              o.x = acc[ph * 2 + 0][t][v];
-              o.y = acc[ph * 2 + 1][t][v];
+          for (int u = 0; u < 8; ++u) {
+            const int v = vb + u, cr = max(min((v & 3) + 8 * (v >> 2), clast), -cbase);
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+              ad[u][ph] = *reinterpret_cast<const float2 *>(addend + obase + (long long)cr * (long long)cstride + ph * W);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int v = vb + u, cr = (v & 3) + 8 * (v >> 2);
+          if (cbase + cr < C) {
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+              float2 o;
+              if (R == 1) {
+                o.x = (ph == 0) ? acc[0][t][v] : 0.f;
+                o.y = 0.f;
+              } else {
+                o.x = acc[ph * 2 + 0][t][v];
+                o.y = acc[ph * 2 + 1][t][v];
+              }
+              if (addend) {
+                o.x += ad[u][ph].x;
+                o.y += ad[u][ph].y;
+              }
+              *reinterpret_cast<float2 *>(dx + obase + cr * cstride + ph * W) = o;
             }
-            if (addend) {
-              const float2 ad = *reinterpret_cast<const float2 *>(addend + oi);
-              o.x += ad.x;
-              o.y += ad.y;
-            }
-            *reinterpret_cast<float2 *>(dx + oi) = o;
           }
         }
       }

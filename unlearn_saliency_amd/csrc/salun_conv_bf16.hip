@@ -323,13 +323,26 @@ void conv_bf16_igemm(const IgArgs g) {
     const float bk = g.bias ? g.bias[k] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      // the epilogue terms of a 32x32 tile are read before its first store, unconditionally (pixels past M re-read the
+      // last one): element by element each load waited alone behind the previous store
+      const int mb = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+      float nv[16];
+      uint16_t av[16];
+      if (g.nbias) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) nv[v] = g.nbias[(size_t)(min(mb + (v & 3) + 8 * (v >> 2), g.M - 1) / ohow) * g.Kout + k];
+      }
+      if (g.addend) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) av[v] = g.addend[(size_t)min(mb + (v & 3) + 8 * (v >> 2), g.M - 1) * g.Kout + k];
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+        const int m = mb + (v & 3) + 8 * (v >> 2);
         if (m < g.M) {
           float o = acc[i][j][v] + bk;
-          if (g.nbias) o += g.nbias[(size_t)(m / ohow) * g.Kout + k];
-          if (g.addend) o += bf2f(g.addend[(size_t)m * g.Kout + k]);
+          if (g.nbias) o += nv[v];
+          if (g.addend) o += bf2f(av[v]);
           g.y[(size_t)m * g.Kout + k] = f2bf(o);
         }
       }
@@ -576,24 +589,46 @@ __global__ __launch_bounds__(256, (R == 3 && ST == 1) ? 2 : 1) void conv_bf16_wg
 
   // ---- partials: part[split][tap][k][c]; D row = k, col = c
   const int c = c0 + wc * 32 + (lane & 31);
+  const bool kw_live = k0 + wk * 32 < g.K;  // wave-uniform: K is a multiple of 32, so are the wave's 32 rows
   if (g.direct) {
     // one split: this workgroup holds the whole sum of its (k, c) tile — a lane owns all R*R taps of an element, i.e.
     // R*R consecutive floats of the OIHW gradient, and the 32 lanes of a row 32*R*R consecutive floats.  (Sending the
     // tile through LDS to store whole rows was measured in round 5: 8x8 layers 67 -> 64 us, 16x16 layers +1 .. +6 us,
     // the stride-2 kernel 92 -> 115 us, the SD step +1 % — the L2 merges the nine partial stores of a line; not kept.)
-    if (c < g.C) {
+    // `+=` (the product path: gradients accumulate into the flat arena) reads the old values of FOUR k rows, 4 * RS
+    // loads in flight, before the first store: written as `dst[t] = accumulate ? dst[t] + a : a` the compiler emitted
+    // load, s_waitcnt vmcnt(0), store for each of the 144 elements — 144 serial trips to memory, 47 of the 69 us of an
+    // 8x8 1280 -> 1280 layer (profiles/r05_wgrad_phases.txt).
+    if (c < g.C && kw_live) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int k = k0 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-        if (k < g.K) {
-          float *dst = g.dw + ((size_t)k * g.C + c) * RS;
+      for (int j = 0; j < 4; ++j) {
+        float *dst = g.dw + ((size_t)(k0 + wk * 32 + 8 * j + 4 * (lane >> 5)) * g.C + c) * RS;
+        const size_t row = (size_t)g.C * RS;
+        if (g.accumulate) {
+          float old[4][RS];
 #pragma unroll
-          for (int t = 0; t < RS; ++t) {
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < RS; ++t) old[q][t] = dst[q * row + t];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < RS; ++t) {
 #if SALUN_BF16_WGRAD_EXP == 1
-            if (acc[t][v] != 12345.678f) continue;
+              if (acc[t][4 * j + q] != 12345.678f) continue;
 #endif
-            dst[t] = g.accumulate ? dst[t] + acc[t][v] : acc[t][v];
-          }
+              dst[q * row + t] = old[q][t] + acc[t][4 * j + q];
+            }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < RS; ++t) {
+#if SALUN_BF16_WGRAD_EXP == 1
+              if (acc[t][4 * j + q] != 12345.678f) continue;
+#endif
+              dst[q * row + t] = acc[t][4 * j + q];
+            }
         }
       }
     }
@@ -632,11 +667,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_bf16(const float *__restri
     }
   __syncthreads();
   const int64_t o0 = i0 * RS, total = kc * RS;
-  for (int idx = threadIdx.x; idx < 64 * RS; idx += 256)
-    if (o0 + idx < total) {
-      float *d = dw + o0 + idx;
-      *d = accumulate ? (*d + sm[idx]) : sm[idx];
-    }
+  float old[3];  // 64 * 9 / 256 -> at most three floats per thread; all old values are read before the first store
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    old[u] = (accumulate && idx < 64 * RS && o0 + idx < total) ? dw[o0 + idx] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int idx = threadIdx.x + 256 * u;
+    if (idx < 64 * RS && o0 + idx < total) dw[o0 + idx] = accumulate ? old[u] + sm[idx] : sm[idx];
+  }
 }
 
 // per-channel sum over pixels of an NHWC bf16 tensor (the bias gradient): [M][K] -> fp32 [K], two deterministic stages.

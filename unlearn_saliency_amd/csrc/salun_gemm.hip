@@ -216,14 +216,24 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const Args a) {
       const int jj = n0 + wn * 32 * WT + y * 32 + lo;
       if (jj >= J.N) continue;
       const float bsv = (direct && J.bias) ? J.bias[jj] : 0.f;
+      // `+=`: the sixteen old values of a tile are read before its first store — element by element every load waited
+      // alone behind the previous store (64 serial trips to memory per lane, see conv_igemm's epilogue in salun_conv.hip)
+      const int ib = m0 + wm * 32 * WT + x * 32 + 4 * hi;
+      float old[16];
+      // unconditional loads (rows past M re-read the last row): a load behind a per-lane test becomes a branch with its
+      // own wait
+      if (direct && J.accumulate) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) old[v] = out[(long long)min(ib + (v & 3) + 8 * (v >> 2), J.M - 1) * ld + jj];
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int ii = m0 + wm * 32 * WT + x * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+        const int ii = ib + (v & 3) + 8 * (v >> 2);
         if (ii >= J.M) continue;
         float *d = out + (long long)ii * ld + jj;
         if (direct) {
           const float r = acc[x][y][v] * a.alpha + bsv;
-          *d = J.accumulate ? (*d + r) : r;
+          *d = J.accumulate ? (old[v] + r) : r;
         } else {
           *d = acc[x][y][v];
         }
@@ -1415,15 +1425,19 @@ __global__ __launch_bounds__(64 * WGA * WGB) void k_gemm_bf16_tn(const TnArgs g)
     const int c = b0 + wb * 64 + b * 32 + lo;
     if (c >= g.Nb) continue;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
+      const int nb = a0 + wa * 64 + a * 32 + 4 * hi;
+      float old[16];  // `+=`: all sixteen old values are read before the first store (no load waits behind a store),
+      if (add) {      // unconditionally: rows past Na re-read the last row
+#pragma unroll
+        for (int v = 0; v < 16; ++v) old[v] = out[(size_t)min(nb + (v & 3) + 8 * (v >> 2), g.Na - 1) * g.Nb + c];
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int n = a0 + wa * 64 + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
-        if (n < g.Na) {
-          float *dst = out + (size_t)n * g.Nb + c;
-          *dst = add ? *dst + acc[a][b][v] : acc[a][b][v];
-        }
+        const int n = nb + (v & 3) + 8 * (v >> 2);
+        if (n < g.Na) out[(size_t)n * g.Nb + c] = add ? old[v] + acc[a][b][v] : acc[a][b][v];
       }
+    }
   }
 }
 

@@ -24,6 +24,7 @@
 // split the reduction over blockIdx.z into fp32 partial images that a second kernel folds in a fixed order (no float
 // atomics anywhere: results are deterministic).
 #include "salun_common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -111,6 +112,23 @@ __device__ __forceinline__ void stage_load(Stage<NV> &st, const float *__restric
   }
 }
 
+// The same share of a chunk that lies wholly inside an operand staged as float4 rows (mode 1 or 2): one float4 per item
+// at a computed address, no guard.  Behind a guard (stage_load) every loaded value is copied into the merged result, and
+// the copy waits for the load: s_waitcnt vmcnt(0) straight after it — the "next chunk's loads fly while this one is
+// multiplied" of the loop below did not hold for a single load (tools/isa_serial_loads.py).
+template <int BT, int NV>
+__device__ __forceinline__ void stage_load_vec(Stage<NV> &st, const float *__restrict__ p, int s_row, int s_k, int r0, int k0,
+                                               int mode, int tid) {
+  constexpr int F4 = BT / 4;
+#pragma unroll
+  for (int r = 0; r < NV; ++r) {
+    const int e = tid + 256 * r;
+    const long long o1 = (long long)(r0 + (e >> 2)) * s_row + k0 + (e & 3) * 4;   // four consecutive k of one row
+    const long long o2 = (long long)(k0 + e / F4) * s_k + r0 + (e % F4) * 4;      // four consecutive rows at one k
+    st.v[r] = *reinterpret_cast<const float4 *>(p + (mode == 1 ? o1 : o2));
+  }
+}
+
 template <int BT, int NV>
 __device__ __forceinline__ void stage_store(float *__restrict__ lds, const Stage<NV> &st, int mode, int tid) {
 #pragma unroll
@@ -169,13 +187,26 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const Args a) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
 
-  if (c_lo < c_hi) {
+  // FAST: the tile lies inside both operands, every segment is staged as float4 rows and is a whole number of chunks ->
+  // the unguarded loads (stage_load_vec); otherwise the guarded ones.  Two copies of the loop, chosen once per workgroup:
+  // a per-chunk choice would merge the two kinds of loaded values again.
+  auto run = [&](auto fastc) {
+    constexpr bool FAST = decltype(fastc)::value;
     int s = J.seg0;
     while (s + 1 < J.seg0 + J.nseg && a.seg[s + 1].chunk0 <= c_lo) ++s;
     Seg S = a.seg[s];
     Stage<NV> ra, rb;
-    stage_load<BT, NV>(ra, S.A + a_off, S.a_i, S.a_k, m0, J.M, (c_lo - S.chunk0) * BK, S.K, S.amode, tid);
-    stage_load<BT, NV>(rb, S.B + b_off, S.b_j, S.b_k, n0, J.N, (c_lo - S.chunk0) * BK, S.K, S.bmode, tid);
+    auto load = [&](int c) {
+      const int k0 = (c - S.chunk0) * BK;
+      if constexpr (FAST) {
+        stage_load_vec<BT, NV>(ra, S.A + a_off, S.a_i, S.a_k, m0, k0, S.amode, tid);
+        stage_load_vec<BT, NV>(rb, S.B + b_off, S.b_j, S.b_k, n0, k0, S.bmode, tid);
+      } else {
+        stage_load<BT, NV>(ra, S.A + a_off, S.a_i, S.a_k, m0, J.M, k0, S.K, S.amode, tid);
+        stage_load<BT, NV>(rb, S.B + b_off, S.b_j, S.b_k, n0, J.N, k0, S.K, S.bmode, tid);
+      }
+    };
+    load(c_lo);
     int amode = S.amode, bmode = S.bmode;
     for (int c = c_lo; c < c_hi; ++c) {
       stage_store<BT, NV>(As, ra, amode, tid);
@@ -183,8 +214,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const Args a) {
       __syncthreads();
       if (c + 1 < c_hi) {  // the next chunk's loads fly while this one is multiplied
         if (s + 1 < J.seg0 + J.nseg && a.seg[s + 1].chunk0 <= c + 1) { ++s; S = a.seg[s]; }
-        stage_load<BT, NV>(ra, S.A + a_off, S.a_i, S.a_k, m0, J.M, (c + 1 - S.chunk0) * BK, S.K, S.amode, tid);
-        stage_load<BT, NV>(rb, S.B + b_off, S.b_j, S.b_k, n0, J.N, (c + 1 - S.chunk0) * BK, S.K, S.bmode, tid);
+        load(c + 1);
         amode = S.amode; bmode = S.bmode;
       }
       const float *ar = As + (wm * 32 * WT + lo) * LDK + hi;
@@ -202,6 +232,15 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const Args a) {
       }
       __syncthreads();
     }
+  };
+  if (c_lo < c_hi) {
+    bool fast = m0 + BT <= J.M && n0 + BT <= J.N;
+    for (int q = J.seg0; q < J.seg0 + J.nseg; ++q) {
+      const Seg &T = a.seg[q];
+      fast = fast && T.amode != 0 && T.bmode != 0 && T.K % BK == 0;
+    }
+    if (fast) run(std::true_type{});
+    else run(std::false_type{});
   }
 
   // ---- epilogue: D[i][j] of a 32x32 tile sits in lane (j = lo, half = hi), register v: i = (v&3) + 8 (v>>2) + 4 hi
@@ -956,6 +995,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BK == 32 && WGM * WGN == 8) ? 4 : 
   }
 #pragma unroll
   for (int pass = 0; pass < EP; ++pass) {
+    // the residual rows of the pass are requested first, all of them and unconditionally (tokens past M re-read the last
+    // one): read one by one next to their stores, each load waited alone behind the previous row's store
+    uint4 adv[8 / EP];
+    if (g.addend) {
+#pragma unroll
+      for (int i = 0; i < 8 / EP; ++i) {
+        const int m = min(m0 + wm * 64 + pass * 32 + i * 8 + (lane >> 3), g.M - 1);
+        adv[i] = *reinterpret_cast<const uint4 *>(g.addend + (size_t)m * g.N + n0 + wn * 64 + fr);
+      }
+    }
 #pragma unroll
     for (int bb = 0; bb < 2 / EP; ++bb) {
       const int b = (EP == 2) ? pass : bb;
@@ -980,7 +1029,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BK == 32 && WGM * WGN == 8) ? 4 : 
                       u1.x + bsv[4], u1.y + bsv[5], u1.z + bsv[6], u1.w + bsv[7]};
         const size_t e = (size_t)m * g.N + n0 + wn * 64 + fr;
         if (g.addend) {
-          const uint4 av = *reinterpret_cast<const uint4 *>(g.addend + e);
+          const uint4 av = adv[i];
           o[0] += gb_lo(av.x); o[1] += gb_hi(av.x); o[2] += gb_lo(av.y); o[3] += gb_hi(av.y);
           o[4] += gb_lo(av.z); o[5] += gb_hi(av.z); o[6] += gb_lo(av.w); o[7] += gb_hi(av.w);
         }
@@ -1171,8 +1220,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
     bsv[0] = b0.x; bsv[1] = b0.y; bsv[2] = b0.z; bsv[3] = b0.w; bsv[4] = b1.x; bsv[5] = b1.y; bsv[6] = b1.z; bsv[7] = b1.w;
   }
   const int ohow = g.OH * g.OW;
+  // The per-image channel offset: a wave's 64 pixels start at a multiple of 64, so with OH * OW a multiple of 64 (every
+  // level of the SD U-Net) they belong to ONE image and its eight values are read once; otherwise per row, as before.
+  const bool one_img = g.nbias && (ohow & 63) == 0;
+  float nb1[8];
+  if (one_img) {
+    const float *nb = g.nbias + (size_t)(min(m0 + wm * 64, g.M - 1) / ohow) * g.Kout + kcol;
+    const float4 n0v = *reinterpret_cast<const float4 *>(nb), n1v = *reinterpret_cast<const float4 *>(nb + 4);
+    nb1[0] = n0v.x; nb1[1] = n0v.y; nb1[2] = n0v.z; nb1[3] = n0v.w; nb1[4] = n1v.x; nb1[5] = n1v.y; nb1[6] = n1v.z; nb1[7] = n1v.w;
+  }
 #pragma unroll
   for (int pass = 0; pass < EP; ++pass) {
+    // the residual rows of the pass are requested first, unconditionally (see k_gemm_bf16_nt_r)
+    uint4 adv[8 / EP];
+    if (g.addend) {
+#pragma unroll
+      for (int i = 0; i < 8 / EP; ++i) {
+        const int m = min(m0 + wm * 64 + pass * 32 + i * 8 + (lane >> 3), g.M - 1);
+        adv[i] = *reinterpret_cast<const uint4 *>(g.addend + (size_t)m * g.Kout + kcol);
+      }
+    }
 #pragma unroll
     for (int bb = 0; bb < 2 / EP; ++bb) {
       const int b = (EP == 2) ? pass : bb;
@@ -1194,7 +1261,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
       if (m < g.M) {
         float o[8] = {u0.x + bsv[0], u0.y + bsv[1], u0.z + bsv[2], u0.w + bsv[3],
                       u1.x + bsv[4], u1.y + bsv[5], u1.z + bsv[6], u1.w + bsv[7]};
-        if (g.nbias) {
+        if (one_img) {
+#pragma unroll
+          for (int e8 = 0; e8 < 8; ++e8) o[e8] += nb1[e8];
+        } else if (g.nbias) {
           const float *nb = g.nbias + (size_t)(m / ohow) * g.Kout + kcol;
           const float4 n0v = *reinterpret_cast<const float4 *>(nb);
           const float4 n1v = *reinterpret_cast<const float4 *>(nb + 4);
@@ -1202,7 +1272,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8) ? 4 : 1) void k_co
         }
         const size_t e = (size_t)m * g.Kout + kcol;
         if (g.addend) {
-          const uint4 av = *reinterpret_cast<const uint4 *>(g.addend + e);
+          const uint4 av = adv[i];
           o[0] += gb_lo(av.x); o[1] += gb_hi(av.x); o[2] += gb_lo(av.y); o[3] += gb_hi(av.y);
           o[4] += gb_lo(av.z); o[5] += gb_hi(av.z); o[6] += gb_lo(av.w); o[7] += gb_hi(av.w);
         }

@@ -1732,14 +1732,75 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce(const float *__restrict
       s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
     }
     const float t[4] = {s4.x, s4.y, s4.z, s4.w};
+    int64_t dst[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t i = i4 * 4 + e;
       const int64_t rs = i / KC, kc = i - rs * KC;
-      const int64_t dst = kc * RS + rs;
-      dw[dst] = accumulate ? dw[dst] + t[e] : t[e];
+      dst[e] = kc * RS + rs;
     }
+    float old[4] = {0.f, 0.f, 0.f, 0.f};  // `+=`: the four old values are read before the first store
+    if (accumulate) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) old[e] = dw[dst[e]];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dw[dst[e]] = accumulate ? old[e] + t[e] : t[e];
   }
+}
+
+// 3x3 layers with many (k, c) pairs: the same sums, written as whole OIHW rows.  conv_wgrad_reduce stores each sum as a
+// lone dword 36 bytes from its neighbour's and the nine taps of a weight from nine different workgroups — for a
+// 512 x 512 layer 2.4 M partial-line writes into a 9.4 MB gradient.  Here a block owns 32 consecutive (k, c) pairs and
+// ALL nine taps: thread (g, rs, q) sums float4 column q of tap rs over the splits g, g + 3, ... (128-byte runs of each
+// partial row), the three groups are folded in LDS in index order, and the 288 sums leave as the 288 consecutive
+// floats they are in dw.  Deterministic: the order depends only on nsplit.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_rows(const float *__restrict__ part, float *__restrict__ dw,
+                                                              int64_t KC, int nsplit, int accumulate) {
+  constexpr int RS = 9, KB = 32, G = 3;
+  __shared__ float4 red[G][RS][KB / 4];
+  __shared__ float outb[KB * RS];
+  const int tid = threadIdx.x, q = tid & 7, r = tid >> 3, rs = r % RS, g = r / RS;  // g == 3: idle (threads 216 .. 255)
+  const int64_t kc0 = (int64_t)blockIdx.x * KB, n4 = KC * RS / 4;
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < G) {
+    const float4 *src = reinterpret_cast<const float4 *>(part + rs * KC + kc0) + q;
+    int j = g;
+    for (; j + 7 * G < nsplit; j += 8 * G) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ldg_stream4(src + (size_t)(j + u * G) * n4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s4.x += v[u].x; s4.y += v[u].y; s4.z += v[u].z; s4.w += v[u].w; }
+    }
+    for (; j < nsplit; j += G) {
+      const float4 v = ldg_stream4(src + (size_t)j * n4);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    red[g][rs][q] = s4;
+  }
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int k = 1; k < G; ++k) {
+      const float4 v = red[k][rs][q];
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    outb[(4 * q + 0) * RS + rs] = s4.x;
+    outb[(4 * q + 1) * RS + rs] = s4.y;
+    outb[(4 * q + 2) * RS + rs] = s4.z;
+    outb[(4 * q + 3) * RS + rs] = s4.w;
+  }
+  __syncthreads();
+  float *d = dw + kc0 * RS;
+  const bool second = tid < KB * RS - 256;
+  float old0 = 0.f, old1 = 0.f;  // `+=`: both old values are read before the first store
+  if (accumulate) {
+    old0 = d[tid];
+    if (second) old1 = d[256 + tid];
+  }
+  d[tid] = accumulate ? old0 + outb[tid] : outb[tid];
+  if (second) d[256 + tid] = accumulate ? old1 + outb[256 + tid] : outb[256 + tid];
 }
 
 // n not a multiple of 4 (odd test shapes; no layer of the three models): one output per thread, splits in order
@@ -1759,6 +1820,16 @@ inline void launch_wgrad_reduce(const float *part, float *dw, int64_t n, int nsp
   if ((n & 3) || !salun_aligned16(part)) {
     hipLaunchKernelGGL(conv_wgrad_reduce_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, dw, n,
                        nsplit, accumulate, KC, RS);
+    return;
+  }
+#ifndef SALUN_WGRAD_REDUCE_ROWS
+#define SALUN_WGRAD_REDUCE_ROWS 1  // 0: lab builds without the whole-row variant
+#endif
+  // whole-row variant: 3x3, at least 1,024 blocks of 32 pairs (below that the blocks do not cover the chip and the
+  // plain kernel's finer split of the work wins)
+  if (SALUN_WGRAD_REDUCE_ROWS && RS == 9 && (KC & 31) == 0 && KC >= 32768) {
+    hipLaunchKernelGGL(conv_wgrad_reduce_rows, dim3((unsigned)(KC / 32)), dim3(256), 0, st, part, dw, (int64_t)KC, nsplit,
+                       accumulate);
     return;
   }
   int logg = 0;

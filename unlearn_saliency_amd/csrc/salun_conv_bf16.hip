@@ -728,17 +728,15 @@ __global__ __launch_bounds__(256) void k_colsum_finish(const float *__restrict__
 }
 
 #ifndef SALUN_BF16_WGRAD_TARGET
-#define SALUN_BF16_WGRAD_TARGET 384
-#endif
-#ifndef SALUN_BF16_WGRAD_FLOOR
-#define SALUN_BF16_WGRAD_FLOOR 0
+#define SALUN_BF16_WGRAD_TARGET 384  // lab builds: other split targets (profiles/r05_wgrad_phases.txt, table 2)
 #endif
 int wgrad_splits(int tiles, int chunks) {
   // about 1.5 workgroups per CU, never more splits than chunks
   // measured on the SD-v1 step (round 3, one box, four builds): 1536 / 768 / 384 / 256 target workgroups ->
-  // 219.3 / 209.3 / 205.7 / 206.6 ms — every split adds a K*C*R*R fp32 partial to write and re-read (59 MB for a
+  // 219.3 / 209.3 / 205.7 / 206.6 ms; again with the paired 3x3 kernel (round 5, layer table): 512 / 384 / 256 ->
+  // 2.39 / 1.99 / 2.08 ms — every split adds a K*C*R*R fp32 partial to write and re-read (59 MB for a
   // 1280x1280 3x3 layer), which costs more than the second resident round of workgroups gives back
-  int s = SALUN_BF16_WGRAD_FLOOR ? SALUN_BF16_WGRAD_TARGET / tiles : (SALUN_BF16_WGRAD_TARGET + tiles - 1) / tiles;
+  int s = (SALUN_BF16_WGRAD_TARGET + tiles - 1) / tiles;
   if (s > chunks) s = chunks;
   if (s > 64) s = 64;
   if (s < 1) s = 1;

@@ -78,10 +78,13 @@ def test_forward_backward_match_library_on_bf16_inputs(shape):
     assert (acc - 1 - dw).abs().max() <= 1e-6 * max(1.0, float(dw.abs().max()))
 
 
-def test_epilogue_terms():
+# (N, H, W, C, K): 64 channels -> the reduction is split and k_splitk_finish carries the terms; 32 channels -> nine stages,
+# no split: conv_bf16_igemm's own epilogue (ragged pixel and channel tiles in the second case)
+@pytest.mark.parametrize("dims", [(2, 8, 8, 64, 64), (2, 8, 8, 32, 32), (1, 5, 7, 32, 96), (3, 16, 16, 32, 160)])
+def test_epilogue_terms(dims):
     from unlearn_saliency_amd import ops
-    N, H, W, C, K = 2, 8, 8, 64, 64
-    x, w = _mk((N, H, W, C), 5), torch.randn(K, C, 3, 3, device="cuda") / 24.0
+    N, H, W, C, K = dims
+    x, w = _mk((N, H, W, C), 5), torch.randn(K, C, 3, 3, device="cuda") / (3.0 * C ** 0.5)
     wp = ops.conv2d_bf16_pack(w)
     nb = torch.randn(N, K, device="cuda")
     add = _mk((N, H, W, K), 6)

@@ -283,6 +283,36 @@ int salun_conv2d_backward_weight(const float *x /*dev*/, const float *dy /*dev*/
                                  int H, int W, int K, int R, int stride, int pad, int P, int Q, int accumulate,
                                  void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 
+/* ------------------------------------------------------------------ K8r --
+ * 3x3 / stride 1 / pad 1 fp32 convolution, forward and backward-data, with both operands fed by LDS-DMA into a
+ * two-stage LDS ring (csrc/salun_conv_ring.hip; round 6) — the same arithmetic as salun_conv2d_forward /
+ * salun_conv2d_backward_data for these shapes (bit-identical results: same exact-fp32 FMA chains in the same order),
+ * i.e. the BasicBlock convolutions of Classification/models/ResNet.py:77-125 and the ResnetBlock convolutions of
+ * DDPM/models/diffusion.py:85-145.  The weights are read from a packed IMAGE of the OIHW tensor (one per direction),
+ * rebuilt by salun_conv3x3_pack_weights whenever the parameters changed (once per optimizer step, all layers in one
+ * launch):
+ *   dgrad = 0: rows = output channels, reduction over input channels   (forward)
+ *   dgrad = 1: rows = input channels, reduction over output channels, taps flipped   (backward-data)
+ * salun_conv3x3_pack_bytes: size of an image (0: the reduction channel count is not a multiple of 8 — not packable).
+ * salun_conv3x3_packed:  y[N,Kout,H,W] = conv3x3(x[N,Cred,H,W], image) (+ bias[Kout]) (+ nbias[N,Kout])
+ *   (+ addend[N,Kout,H,W], may alias y); forward: x = input, Cred = C, Kout = K, image dgrad = 0; backward-data:
+ *   x = dy, Cred = K, Kout = C, image dgrad = 1.  W in {4, 8, 16, 32}, the pixel space must tile into whole rows /
+ *   whole images (SALUN_EINVAL otherwise: the caller uses salun_conv2d_*).  `cfg`: 0 = tile chosen from the problem;
+ *   low byte 1..5 pins a tile, bits 8.. the workgroups per CU of the persistent grid (tuning: tools/convring_bench.py). */
+size_t salun_conv3x3_pack_bytes(int K, int C, int dgrad);
+#define SALUN_PACK_MAX_JOBS 32
+typedef struct {
+  const float *w;   /* dev, OIHW [K, C, 3, 3] */
+  float *img_fwd;   /* dev, salun_conv3x3_pack_bytes(K, C, 0) bytes, or NULL (needs C % 8 == 0) */
+  float *img_dgrad; /* dev, salun_conv3x3_pack_bytes(K, C, 1) bytes, or NULL (needs K % 8 == 0) */
+  int32_t K, C;
+} salun_pack_job_t;
+/* Both images of `njobs` layers; one launch per SALUN_PACK_MAX_JOBS layers (`jobs` is a HOST array). */
+int salun_conv3x3_pack_weights(const salun_pack_job_t *jobs /*host*/, int njobs, salun_stream_t stream);
+int salun_conv3x3_packed(const float *x /*dev*/, const float *img /*dev*/, const float *bias /*dev or NULL*/,
+                         const float *nbias /*dev or NULL*/, const float *addend /*dev or NULL*/, float *y /*dev*/,
+                         int N, int Cred, int H, int W, int Kout, int cfg, salun_stream_t stream);
+
 /* ------------------------------------------------------------------ K11 --
  * bf16 2-D convolution on the matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulators): the convolutions of the
  * Stable-Diffusion U-Net in its bf16 configuration (BASELINE.json configs[4]) — replaces the library calls autograd

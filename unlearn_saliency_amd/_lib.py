@@ -39,6 +39,12 @@ class GemmJob(ctypes.Structure):
                 ("accumulate", ctypes.c_int32)]
 
 
+class PackJob(ctypes.Structure):
+    """salun_pack_job_t"""
+    _fields_ = [("w", c_void_p), ("img_fwd", c_void_p), ("img_dgrad", c_void_p), ("K", ctypes.c_int32),
+                ("C", ctypes.c_int32)]
+
+
 SALUN_GEMM_MAX_JOBS = 32
 SALUN_GEMM_MAX_SEGS = 32
 
@@ -84,6 +90,9 @@ SIGNATURES = {
     "salun_channel_sum_workspace_bytes": (c_size_t, [c_int] * 2),
     "salun_channel_sum": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int] * 6),
+    "salun_conv3x3_pack_bytes": (c_size_t, [c_int] * 3),
+    "salun_conv3x3_pack_weights": (c_int, [c_void_p, c_int, c_void_p]),
+    "salun_conv3x3_packed": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "salun_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_size_t,
                                                                                           c_void_p]),
     "salun_conv2d_bf16_supported": (c_int, [c_int] * 5),

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import dist as sdist
-from . import gradsink, ops, resblock
+from . import gradsink, ops, resblock, ringpack
 
 
 # calls that went to the library (MIOpen) instead of the MFMA kernels, by reason
@@ -31,6 +31,10 @@ _STRICT = [False]
 _BLOCK_NODES = [os.environ.get("SALUN_BLOCK_NODES", "1") != "0"]
 # SALUN_OWN_GEMM=0: keep the diffusion U-Nets' Linear layers and fp32 attention on the library (A/B switch)
 _OWN_GEMM = [os.environ.get("SALUN_OWN_GEMM", "1") != "0"]
+
+
+# SALUN_RING=0: keep every 3x3 convolution on conv_igemm (A/B switch for the benchmarks)
+_RING = [os.environ.get("SALUN_RING", "1") != "0"]
 
 
 def strict(on: bool = True) -> None:
@@ -173,4 +177,10 @@ def use_salun_convs(model: nn.Module) -> int:
         if type(mod) is nn.Conv2d and _eligible(mod) and id(mod) not in owners:
             mod.__class__ = SalunConv2d
             n += 1
+    # 3x3 / stride 1 / pad 1 layers: forward and backward-data on the LDS-DMA ring kernel (csrc/salun_conv_ring.hip),
+    # which reads packed weight images — all layers of the model re-packed in one launch per optimizer step
+    if _RING[0]:
+        ringpack.register([m.weight for m in model.modules()
+                           if isinstance(m, nn.Conv2d) and _eligible(m) and m.kernel_size == (3, 3)
+                           and m.stride == (1, 1) and m.padding == (1, 1)])
     return n

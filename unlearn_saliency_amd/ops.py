@@ -13,7 +13,7 @@ import torch
 
 from .fastfn import FastFunction
 
-from . import _lib
+from . import _lib, ringpack
 from ._lib import c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p, check
 
 
@@ -350,11 +350,17 @@ def conv2d_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     outside the kernel's tiling domain."""
     N, C, H, W = x.shape
     K, _, R, _ = w.shape
-    y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
     if nbias is not None and tuple(nbias.shape) != (N, K):
         raise ValueError(f"nbias must be [{N}, {K}], got {tuple(nbias.shape)}")
     if addend is not None and tuple(addend.shape) != (N, K, P, Q):
         raise ValueError(f"addend must be {(N, K, P, Q)}, got {tuple(addend.shape)}")
+    if R == 3 and stride == 1 and pad == 1 and P == H and Q == W:
+        imgs = ringpack.images(w)  # registered weights (conv.use_salun_convs): the LDS-DMA ring kernel, K8r
+        if imgs is not None:
+            y = conv3x3_packed(x, imgs[0], K, bias=bias, nbias=nbias, addend=addend)
+            if y is not None:
+                return y
+    y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     wsb = _data_ws_bytes(N, K, P, Q, R, stride)  # > 0 only for under-filled launches
     ws = workspace(wsb, x.device) if wsb else None
@@ -376,6 +382,12 @@ def conv2d_backward_data(dy: torch.Tensor, w: torch.Tensor, x_shape, stride: int
     N, C, H, W = x_shape
     K, _, R, _ = w.shape
     P, Q = dy.shape[2], dy.shape[3]
+    if R == 3 and stride == 1 and pad == 1 and P == H and Q == W:
+        imgs = ringpack.images(w)
+        if imgs is not None:
+            dx = conv3x3_packed(dy, imgs[1], C, addend=addend)
+            if dx is not None:
+                return dx
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
     L = _lib.lib()
     wsb = _data_ws_bytes(N, C, H, W, R, 1) if stride == 1 else 0
@@ -411,6 +423,44 @@ def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: i
         return None
     check(rc, "salun_conv2d_backward_weight")
     return dw
+
+
+# ----------------------------------------------------------------------------- K8r
+# 3x3 / stride 1 / pad 1 convolution on the LDS-DMA ring kernel (csrc/salun_conv_ring.hip): packed weight images.
+def conv3x3_pack(w: torch.Tensor, dgrad: bool, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Packed image of an OIHW [K, C, 3, 3] weight for the forward (dgrad=False) or backward-data (dgrad=True) walk;
+    None when the reduction channel count is not a multiple of 8 (the caller keeps the conv_igemm path).  (Models pack
+    all their layers in one launch through ringpack.py; this is the single-image form for tools and tests.)"""
+    K, C = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    nbytes = int(L.salun_conv3x3_pack_bytes(K, C, int(dgrad)))
+    if nbytes == 0 or tuple(w.shape[2:]) != (3, 3):
+        return None
+    img = out if out is not None and out.numel() * 4 == nbytes else torch.empty(nbytes // 4, dtype=torch.float32,
+                                                                                device=w.device)
+    _dev(w, torch.float32, "w")
+    job = _lib.PackJob(w.data_ptr(), None if dgrad else img.data_ptr(), img.data_ptr() if dgrad else None, K, C)
+    check(L.salun_conv3x3_pack_weights(ctypes.cast(ctypes.pointer(job), c_void_p), 1, _stream()),
+          "salun_conv3x3_pack_weights")
+    return img
+
+
+def conv3x3_packed(x: torch.Tensor, img: torch.Tensor, Kout: int, bias: Optional[torch.Tensor] = None,
+                   nbias: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None, cfg: int = 0) -> Optional[torch.Tensor]:
+    """y[N, Kout, H, W] = conv3x3(x[N, Cred, H, W], packed image) (+ bias) (+ nbias[n, k]) (+ addend); None outside the
+    kernel's tiling domain.  `out` may be the addend (accumulate in place)."""
+    N, Cred, H, W = x.shape
+    y = out if out is not None else torch.empty((N, Kout, H, W), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().salun_conv3x3_packed(_dev(x, torch.float32, "x"), c_void_p(img.data_ptr()),
+                                         _dev(bias, torch.float32, "bias", True),
+                                         _dev(nbias, torch.float32, "nbias", True),
+                                         _dev(addend, torch.float32, "addend", True), c_void_p(y.data_ptr()),
+                                         N, Cred, H, W, Kout, int(cfg), _stream())
+    if rc == _lib.SALUN_EINVAL:
+        return None
+    check(rc, "salun_conv3x3_packed")
+    return y
 
 
 def channel_sum(dy: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:

@@ -282,6 +282,14 @@ size_t salun_conv2d_wgrad_workspace_bytes(int N, int C, int K, int R, int P, int
 int salun_conv2d_backward_weight(const float *x /*dev*/, const float *dy /*dev*/, float *dw /*dev*/, int N, int C,
                                  int H, int W, int K, int R, int stride, int pad, int P, int Q, int accumulate,
                                  void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
+/* The same with scheduling hints.  SALUN_WGRAD_SHARED: the launch runs on a side stream BESIDE other kernels of the
+ * step (resblock.py overlaps backward-weight with backward-data and the normalisation backward): 3x3 / stride 1 layers
+ * then keep the register-staged kernel; without the flag they run on the LDS-DMA ring kernel (csrc/salun_conv_ring.hip:
+ * 12 - 18 % faster alone).  Both are deterministic; their results differ by the summation order over the pixels. */
+#define SALUN_WGRAD_SHARED 1u
+int salun_conv2d_backward_weight_ex(const float *x /*dev*/, const float *dy /*dev*/, float *dw /*dev*/, int N, int C,
+                                    int H, int W, int K, int R, int stride, int pad, int P, int Q, int accumulate,
+                                    unsigned flags, void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 
 /* ------------------------------------------------------------------ K8r --
  * 3x3 / stride 1 / pad 1 fp32 convolution, forward and backward-data, with both operands fed by LDS-DMA into a

@@ -162,3 +162,23 @@ def test_gradients_through_the_ring_path_match_the_igemm_path():
             ringpack.ENABLED[0] = True
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,C,H,K", [(16, 64, 32, 64), (16, 128, 16, 128), (16, 256, 8, 256), (32, 512, 4, 512),
+                                     (3, 64, 8, 64), (4, 384, 16, 256), (2, 320, 32, 320), (5, 64, 4, 96)])
+def test_ring_backward_weight_matches_torch_cpu(N, C, H, K):
+    """conv3x3_wgrad_ring (the default 3x3 / stride 1 backward-weight when the launch is not flagged as sharing the
+    device) against PyTorch on the CPU; deterministic; and the flagged launch (conv_wgrad_v) agrees to rounding."""
+    from unlearn_saliency_amd import ops
+    x, dy = _rand((N, C, H, H), 1), _rand((N, K, H, H), 4)
+    dw_ref = torch.nn.grad.conv2d_weight(x, (K, C, 3, 3), dy, 1, 1)
+    xd, dyd = x.cuda(), dy.cuda()
+    dw = ops.conv2d_backward_weight(xd, dyd, (K, C, 3, 3), 1, 1)
+    tol = 6e-6 * float(dw_ref.abs().max())
+    assert dw is not None and torch.allclose(dw.cpu(), dw_ref, rtol=3e-6, atol=tol)
+    assert torch.equal(dw, ops.conv2d_backward_weight(xd, dyd, (K, C, 3, 3), 1, 1))
+    dws = ops.conv2d_backward_weight(xd, dyd, (K, C, 3, 3), 1, 1, shared=True)
+    assert torch.allclose(dws.cpu(), dw_ref, rtol=3e-6, atol=tol)
+    acc = _rand((K, C, 3, 3), 9).cuda()
+    got = ops.conv2d_backward_weight(xd, dyd, (K, C, 3, 3), 1, 1, out=acc.clone(), accumulate=True)
+    assert torch.allclose(got, acc + dw, rtol=1e-6, atol=tol)

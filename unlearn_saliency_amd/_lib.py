@@ -22,6 +22,7 @@ SALUN_EIO = -5
 SALUN_MAX_THRESHOLDS = 16
 SALUN_TOPK_FORCE_FULL_SCAN = 1
 SALUN_TOPK_VALUES_ONLY = 2
+SALUN_WGRAD_SHARED = 1
 
 c_void_p, c_int, c_int64, c_uint64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64
 c_double, c_size_t = ctypes.c_double, ctypes.c_size_t
@@ -95,6 +96,8 @@ SIGNATURES = {
     "salun_conv3x3_packed": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "salun_conv2d_backward_weight": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_size_t,
                                                                                           c_void_p]),
+    "salun_conv2d_backward_weight_ex": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [ctypes.c_uint, c_void_p,
+                                                                                                 c_size_t, c_void_p]),
     "salun_conv2d_bf16_supported": (c_int, [c_int] * 5),
     "salun_conv2d_bf16_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "salun_conv2d_bf16_data_workspace_bytes": (c_size_t, [c_int] * 8),

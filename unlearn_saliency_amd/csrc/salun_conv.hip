@@ -30,6 +30,10 @@
 #include <mutex>
 #include <unordered_set>
 
+// salun_conv_ring.hip: the LDS-DMA ring form of the 3x3 / stride 1 backward-weight (SALUN_EINVAL = not its shape)
+int salun_ring_wgrad_launch(const float *x, const float *dy, float *part, int N, int C, int H, int W, int K, int nsplit,
+                            int nchunks, hipStream_t st);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -62,6 +66,10 @@ constexpr int igemm_chunk(int R, int stride) { return (R == 1 && stride == 1) ? 
 // the four-wave kernel and this one stays as a build option.
 #ifndef SALUN_WGRAD_8WAVES
 #define SALUN_WGRAD_8WAVES 0
+#endif
+// 1 = keep the 3x3 stride-1 backward-weight on conv_wgrad_v (A/B builds against the ring kernel of salun_conv_ring.hip)
+#ifndef SALUN_WGRAD_NO_RING
+#define SALUN_WGRAD_NO_RING 0
 #endif
 
 struct ConvGeomUnused {
@@ -2385,6 +2393,12 @@ SALUN_EXPORT int salun_channel_sum(const float *dy, float *out, int N, int K, in
 SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, float *dw, int N, int C, int H, int W,
                                               int K, int R, int stride, int pad, int P, int Q, int accumulate,
                                               void *ws, size_t ws_bytes, salun_stream_t stream) {
+  return salun_conv2d_backward_weight_ex(x, dy, dw, N, C, H, W, K, R, stride, pad, P, Q, accumulate, 0, ws, ws_bytes, stream);
+}
+
+SALUN_EXPORT int salun_conv2d_backward_weight_ex(const float *x, const float *dy, float *dw, int N, int C, int H, int W,
+                                                 int K, int R, int stride, int pad, int P, int Q, int accumulate,
+                                                 unsigned flags, void *ws, size_t ws_bytes, salun_stream_t stream) {
   if (!x || !dy || !dw || !ws || N < 1 || C < 1 || K < 1 || P < 1 || Q < 1) return SALUN_EINVAL;
   if (!((R == 3 || R == 1) && (stride == 1 || stride == 2))) return SALUN_EINVAL;
   if (R == 1 && pad == 0 && C >= 32 && H == P * stride && W == Q * stride && W % 4 == 0 && salun_aligned16(x) &&
@@ -2449,9 +2463,21 @@ SALUN_EXPORT int salun_conv2d_backward_weight(const float *x, const float *dy, f
   if (ldsb > 160 * 1024) return SALUN_EINVAL;
   dim3 grid((K + 63) / 64, (C + 63) / 64, ns);
   float *part = static_cast<float *>(ws);
-  // vectorised staging (conv_wgrad_v) where the geometry allows it: 3x3, pad 1, full channel tiles, whole image rows
+  // 3x3 / stride 1 / pad 1 on square images: the LDS-DMA ring kernel (salun_conv_ring.hip)
   bool vec_done = false;
-  if (R == 3 && pad == 1 && C % 64 == 0 && W % 4 == 0 && Q * stride == W && P * stride == H && salun_aligned16(x) &&
+  // ... unless the caller says the launch shares the device with another stream's kernels (SALUN_WGRAD_SHARED): beside a
+  // second matrix kernel or a BatchNorm pass on the same SIMDs the ring kernel's dense MFMA stream buys nothing and costs
+  // its neighbours more than conv_wgrad_v's does (round 6: ResNet-18 step 117.5 vs 116.1 steps/s, DDPM 9.59 vs 9.46 with
+  // backward-weight on the side stream; alone it is 12 - 18 % faster, and the single-stream step 111.8 vs 107.9)
+#if !SALUN_WGRAD_NO_RING
+  if (R == 3 && stride == 1 && pad == 1 && P == H && Q == W && pixc == 64 && !(flags & SALUN_WGRAD_SHARED)) {
+    const int rc = salun_ring_wgrad_launch(x, dy, part, N, C, H, W, K, ns, g.ntiles, st);
+    if (rc == SALUN_OK) vec_done = true;
+    else if (rc != SALUN_EINVAL) return rc;
+  }
+#endif
+  // vectorised staging (conv_wgrad_v) where the geometry allows it: 3x3, pad 1, full channel tiles, whole image rows
+  if (!vec_done && R == 3 && pad == 1 && C % 64 == 0 && W % 4 == 0 && Q * stride == W && P * stride == H && salun_aligned16(x) &&
       salun_aligned16(dy) && (size_t)g.NI * C * H * W < (1u << 30)) {
     const int F4C = g.NI * g.IH_t * (W / 4);
     const int nit = (F4C % 4 == 0) ? F4C / 4 : 0;

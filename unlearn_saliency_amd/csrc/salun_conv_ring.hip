@@ -31,6 +31,12 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) char *ring_lds_ptr_t;
 
+// Tuning switch (0 in the product build; tools/lab_build.sh builds A/B libraries with it — results are WRONG with a bit
+// set): conv3x3_wgrad_ring  1 no DMA after the first chunk   2 no MFMAs   4 no partial-sum stores
+#ifndef SALUN_WGR_EXP
+#define SALUN_WGR_EXP 0
+#endif
+
 constexpr int RCC = 8;      // reduction channels per chunk
 constexpr int RSTEPS = 36;  // k-steps per chunk: (RCC / 2) channel pairs x 9 taps
 constexpr int RGROUPS = 9;  // 16-byte A groups per chunk and 32-row tile (4 k-steps each)
@@ -99,6 +105,7 @@ struct RingArgs {
   const float *bias;    // [Kout] or null
   const float *nbias;   // [N][Kout] or null
   const float *addend;  // [N][Kout][H][W] or null (may alias y)
+  const float *zero;    // g_ring_zero
   float *y;             // [N][Kout][H][W]
   int N, Cred, H, Kout;
   int NI, TP;           // images per tile, rows per image per tile
@@ -157,13 +164,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
       const bool act = e < npiece;
       const bool valid = act && n < N && ih >= 0 && ih < H;
       pact[j] = act;
-      psrc[j] = valid ? g.x + ((size_t)(n * Cred + c) * H + ih) * W + 4 * col4 : g_ring_zero + 4 * lane;
+      psrc[j] = valid ? g.x + ((size_t)(n * Cred + c) * H + ih) * W + 4 * col4 : g.zero + 4 * lane;
       pstep[j] = valid ? RCC * HW : 0;
     }
 #pragma unroll
     for (int j = 0; j < NAW; ++j) {
       const int a = wave + 4 * j, t = a / RGROUPS, gq = a - t * RGROUPS;
-      asrc[j] = g.aimg + ((size_t)(kb * KTW + t) * nchunk * RGROUPS + gq) * 256 + 4 * lane;
+      // a channel block that hangs over the last 32-row tile of the image re-reads that tile (the image ends there; its
+      // results are masked in the epilogue)
+      const int rt = min(kb * KTW + t, (g.Kout + 31) / 32 - 1);
+      asrc[j] = g.aimg + ((size_t)rt * nchunk * RGROUPS + gq) * 256 + 4 * lane;
     }
   };
   auto issue = [&](int chunk, int stage) {
@@ -185,6 +195,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
     }
   };
 
+  // (Tried and measured, round 6: s_setprio 1 .. 3 for the whole kernel, so that backward-data wins the matrix pipe
+  // against the side stream's backward-weight wave on its SIMD — the ResNet-18 step got 0.5 - 1.5 % SLOWER at every level,
+  // and the same on the backward-weight side: the two streams finish together best when the hardware arbitrates.)
   const int total = g.ntiles;
   int it_tile = blockIdx.x, it_chunk = 0;
   if (it_tile < total) {
@@ -338,12 +351,230 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward-weight, 3x3 / stride 1 / pad 1, square images of width 4 .. 32:  dW[k][c][r][s] = sum_pix dY[k][pix] X[c][pix + (r-1, s-1)].
+// Same tile as conv_wgrad_v (salun_conv.hip): workgroup = 64 k x 64 c, wave = 32 k x 32 c x 9 taps (144 accumulator
+// registers, one wave per SIMD), the pixels in chunks of 64, partial sums [split][tap][k][c] -> conv_wgrad_reduce.
+// What changes is how the operands travel and how they are read:
+//   * chunk i+1 goes global -> LDS by LDS-DMA (16-byte pieces of dY rows and of patch rows; patch rows outside the
+//     image come from the page of zeros) while chunk i is multiplied: no global_load / ds_write_b32 instruction pairs
+//     dealt over the MFMA slots (conv_wgrad_v: 12 + 48 per thread and chunk), one raw s_barrier per chunk;
+//   * LDS rows are [channel][pixels] with a row length of an ODD number of 16-byte pieces, read with ds_read_b128:
+//     conflict-free across the 32 rows of an operand, and a lane gets FOUR consecutive pixels — four MFMA steps — per
+//     read.  The reduction index of an MFMA step is a pixel, so any pairing works as long as A and B agree: half `hi`
+//     of the wave takes pixels 8m + 4hi + e at step 4m + e;
+//   * the nine taps of those four pixels need, per patch row, the pixels q0-1 .. q0+4: one aligned ds_read_b128 plus the
+//     two neighbours as ds_read_b32 (zero where the neighbour is outside the image row: a compile-time property of
+//     (m, hi), applied with one v_cndmask).  The B operand of tap (r, s) at step e is then simply register e + s of
+//     that row's six: 10 LDS reads per 36 MFMAs where conv_wgrad_v issues 40.
+// Summation order over the pixels differs from conv_wgrad_v's (same exact-fp32 FMA chains, other pairing).
+struct WgradRingArgs {
+  const float *x;     // [N][C][H][W]
+  const float *dy;    // [N][K][H][W]
+  const float *zero;  // g_ring_zero (its address as an argument: taken in the kernel it is re-loaded from the GOT at every use)
+  float *part;        // [nsplit][9][K][C]
+  int N, C, K, nchunks;
+};
+
+template <int LOGW>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_ring(const WgradRingArgs g) {
+  constexpr int W = 1 << LOGW, W4 = W / 4, H = W;
+  constexpr int TP = (W * W >= 64) ? 64 / W : W;       // image rows per chunk
+  constexpr int NI = (W * W >= 64) ? 1 : 64 / (W * W);  // images per chunk
+  constexpr int PRI = TP + 2;                           // patch rows per image
+  constexpr int PSZ4 = NI * PRI * W4;                   // 16-byte pieces per channel row of the patch
+  constexpr int PRX = PSZ4 | 1;                         // ... padded to an odd count
+  constexpr int DRW = 17;                               // pieces per dY row (16 + 1)
+  constexpr int D_BYTES = 64 * DRW * 16, X_BYTES = 64 * PRX * 16, STAGE = D_BYTES + X_BYTES;
+  constexpr int NDU = DRW, NXU = PRX;                   // DMA units (64 pieces) of a chunk: dY, patch
+  constexpr int NDW = (NDU + 3) / 4, NXW = (NXU + 3) / 4;  // ... per wave
+  constexpr int TPI = (NI > 1) ? 1 : H / TP;            // chunks per image
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(ring_lds_ptr_t)lds;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int kt = wave & 1, ct = wave >> 1;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int split = blockIdx.z, nsplit = gridDim.z;
+  const int N = g.N, C = g.C, K = g.K;
+  constexpr int HW = H * W;
+
+  // ---- this wave's DMA units.  Source of a piece = chunk base (wave-uniform, SALU) + lane offset (fixed for the kernel);
+  // what depends on the chunk per lane is only whether the piece exists (image beyond N, patch row outside the image):
+  // a few compares and two selects per unit in the MFMA slot that issues it.
+  constexpr int NEVER = 1 << 24;        // image index of the pad pieces: never inside the batch
+  int d_lane[NDW], d_ni[NDW];
+#pragma unroll
+  for (int j = 0; j < NDW; ++j) {
+    const int e = (wave + 4 * j) * 64 + lane;
+    const int k = e / DRW, pc = e - k * DRW;  // pc == 16: the pad piece
+    const int pix = 4 * pc;                   // pixel inside the chunk: (ni, p, q) flattened
+    const int ni = pix / (TP * W), rem = pix - ni * (TP * W);
+    d_ni[j] = (pc == 16 || k0 + k >= K) ? NEVER : ni;
+    d_lane[j] = (ni * K + k) * HW + rem;      // from &dy[n0][k0][p0][0]
+  }
+  int x_lane[NXW], x_ni[NXW], x_rr[NXW];
+#pragma unroll
+  for (int j = 0; j < NXW; ++j) {
+    const int e = (wave + 4 * j) * 64 + lane;
+    const int c = e / PRX, pc = e - c * PRX;
+    const int row = pc / W4, col4 = pc - row * W4;
+    const int ni = row / PRI, rr = row - ni * PRI;
+    x_ni[j] = (pc >= PSZ4) ? NEVER : ni;
+    x_rr[j] = rr;
+    x_lane[j] = ((ni * C + c) * H + rr) * W + 4 * col4;  // from &x[n0][c0][p0 - 1][0]
+  }
+  const float *const zero = g.zero + 4 * lane;
+  // one DMA unit of the chunk `chunk` into stage `stage`: u < NDW: dY unit u, else patch unit u - NDW
+  auto issue_unit = [&](int u, int chunk, int stage) {
+    int n0, p0;
+    if (NI > 1) { n0 = chunk * NI; p0 = 0; }
+    else { n0 = chunk / TPI; p0 = (chunk - n0 * TPI) * TP; }
+    const unsigned base = lds_base + stage * STAGE;
+    if (u < NDW) {
+      const int j = u;
+      if ((wave + 4 * j) < NDU) {
+        const float *src = g.dy + ((size_t)(n0 * K + k0) * H + p0) * W;
+        const float *p = (d_ni[j] < N - n0) ? src + d_lane[j] : zero;
+        ring_dma16(p, base + (wave + 4 * j) * 1024);
+      }
+    } else {
+      const int j = u - NDW;
+      if ((wave + 4 * j) < NXU) {
+        const float *src = g.x + ((long long)(n0 * C + c0) * H + (p0 - 1)) * W;
+        const bool ok = x_ni[j] < N - n0 && x_rr[j] >= 1 - p0 && x_rr[j] < H + 1 - p0;
+        const float *p = ok ? src + x_lane[j] : zero;
+        ring_dma16(p, base + D_BYTES + (wave + 4 * j) * 1024);
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  if (split < g.nchunks) {
+#pragma unroll
+    for (int u = 0; u < NDW + NXW; ++u) issue_unit(u, split, 0);
+    int stage = 0;
+    const int a_lane = (kt * 32 + lo) * (DRW * 16) + hi * 16;
+    const int b_lane = D_BYTES + (ct * 32 + lo) * (PRX * 16) + hi * 16;
+    for (int chunk = split; chunk < g.nchunks; chunk += nsplit) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's units of the chunk (requested a chunk ago) have landed
+      __builtin_amdgcn_s_barrier();        // ... everyone's have, and everyone is done reading the other stage
+      const int nxt_chunk = chunk + nsplit;
+      const bool more = nxt_chunk < g.nchunks;
+      const char *A = lds + stage * STAGE + a_lane;
+      const char *B = lds + stage * STAGE + b_lane;
+      // operands of pixel group m: A = 4 pixels of dY; B rows r = 0..2: {left neighbour, 4 pixels, right neighbour}
+      // (plain scalars on purpose: as [3][6] arrays passed to the reading lambdas the neighbours were kept in scratch)
+      struct Row { float l; float4 v; float r; };
+      struct Ops { float4 a; Row b0, b1, b2; };
+      auto group_off = [&](int m) {  // float offset of pixel group 2m (half 0) inside a patch channel row, tap row 0
+        const int pix = 8 * m, ni = pix / (TP * W), rem = pix - ni * (TP * W), p = rem / W, q0 = rem - p * W;
+        return (ni * PRI + p) * W + q0;
+      };
+      auto read_row = [&](int off) {
+        Row o;
+        o.v = *reinterpret_cast<const float4 *>(B + off);
+        if (W > 4) {
+          o.l = *reinterpret_cast<const float *>(B + off - 4);
+          o.r = *reinterpret_cast<const float *>(B + off + 16);
+        } else {
+          o.l = 0.f;
+          o.r = 0.f;
+        }
+        return o;
+      };
+      auto read_group = [&](int m) {
+        Ops o;
+        o.a = *reinterpret_cast<const float4 *>(A + m * 32);
+        const int off = group_off(m) * 4;
+        o.b0 = read_row(off);
+        o.b1 = read_row(off + W * 4);
+        o.b2 = read_row(off + 2 * W * 4);
+        return o;
+      };
+      auto mask_row = [&](int m, Row o) {  // neighbours outside the image row
+        if (W > 4) {
+          const int q00 = (8 * m) & (W - 1);
+          if (q00 == 0) o.l = hi ? o.l : 0.f;        // half 0 starts the row
+          if (q00 == W - 8) o.r = hi ? 0.f : o.r;    // half 1 ends it
+        }
+        return o;
+      };
+      auto pick = [](const Row &o, int i) {  // i = e + s: pixel q0 - 1 + i
+        return i == 0 ? o.l : i == 1 ? o.v.x : i == 2 ? o.v.y : i == 3 ? o.v.z : i == 4 ? o.v.w : o.r;
+      };
+      Ops cur = read_group(0), nxt = cur;
+      cur.b0 = mask_row(0, cur.b0); cur.b1 = mask_row(0, cur.b1); cur.b2 = mask_row(0, cur.b2);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        if (m + 1 < 8) nxt = read_group(m + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float av = e == 0 ? cur.a.x : e == 1 ? cur.a.y : e == 2 ? cur.a.z : cur.a.w;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const float bv = pick(t / 3 == 0 ? cur.b0 : t / 3 == 1 ? cur.b1 : cur.b2, e + t % 3);
+            if (!(SALUN_WGR_EXP & 2)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            else asm volatile("" ::"v"(av), "v"(bv));
+            if (t == 0) {
+              // one DMA unit of the next chunk per MFMA step (first half of the chunk), between two MFMAs
+              __builtin_amdgcn_sched_barrier(0);
+              const int u = 4 * m + e;
+              if (u < NDW + NXW && more && !(SALUN_WGR_EXP & 1)) issue_unit(u, nxt_chunk, stage ^ 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (m + 1 < 8) {
+          cur.a = nxt.a;
+          cur.b0 = mask_row(m + 1, nxt.b0); cur.b1 = mask_row(m + 1, nxt.b1); cur.b2 = mask_row(m + 1, nxt.b2);
+        }
+      }
+      stage ^= 1;
+    }
+  }
+  static_assert(NDW + NXW <= 32, "one DMA unit per MFMA step");
+  float *out = g.part + (size_t)split * K * C * 9;
+  const int c = c0 + ct * 32 + lo;
+  if ((SALUN_WGR_EXP & 4) && K > 0) return;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int k = k0 + kt * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+      if (k < K) out[((size_t)t * K + k) * C + c] = acc[t][v];
+    }
+}
+
 inline void ring_allow_lds(const void *fn) {
   static std::mutex mu;
   static std::unordered_set<uintptr_t> done;
   std::lock_guard<std::mutex> lk(mu);
   if (done.insert(reinterpret_cast<uintptr_t>(fn) ^ ((uintptr_t)(salun_device_bit() + 1) << 56)).second)
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// device address of the page of zeros (per device, looked up once)
+inline const float *ring_zero_page() {
+  static const float *page[64] = {nullptr};
+  static std::mutex mu;
+  const int b = salun_device_bit();
+  std::lock_guard<std::mutex> lk(mu);
+  if (!page[b]) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ring_zero)) != hipSuccess) return nullptr;
+    page[b] = static_cast<const float *>(p);
+  }
+  return page[b];
 }
 
 inline int ring_cu_count() {
@@ -426,6 +657,38 @@ int ring_dispatch(const RingArgs &a, int cfg, bool epi, int wgs_per_cu, hipStrea
 
 }  // namespace
 
+// Called by salun_conv2d_backward_weight (salun_conv.hip) for 3x3 / stride 1 / pad 1 layers before its own kernels:
+// SALUN_EINVAL = not this kernel's shape.  `part` = [nsplit][9][K][C], nchunks = 64-pixel chunks of the batch.
+int salun_ring_wgrad_launch(const float *x, const float *dy, float *part, int N, int C, int H, int W, int K, int nsplit,
+                            int nchunks, hipStream_t st) {
+  if (H != W || C % 64 != 0 || K % 32 != 0 || !salun_aligned16(x) || !salun_aligned16(dy)) return SALUN_EINVAL;
+  if ((long long)N * C * H * W >= (1ll << 31) || (long long)N * K * H * W >= (1ll << 31)) return SALUN_EINVAL;
+  const float *zero = ring_zero_page();
+  if (!zero) return SALUN_EIO;
+  WgradRingArgs a{x, dy, zero, part, N, C, K, nchunks};
+  dim3 grid((K + 63) / 64, C / 64, nsplit);
+#define SALUN_WGR(LOGW_)                                                                                        \
+  {                                                                                                             \
+    constexpr int W_ = 1 << LOGW_, TP_ = (W_ * W_ >= 64) ? 64 / W_ : W_, NI_ = (W_ * W_ >= 64) ? 1 : 64 / (W_ * W_);  \
+    constexpr int PRX_ = (NI_ * (TP_ + 2) * (W_ / 4)) | 1;                                                      \
+    const size_t ldsb = 2 * (size_t)(64 * 17 * 16 + 64 * PRX_ * 16);                                            \
+    const int want = (NI_ > 1) ? (N + NI_ - 1) / NI_ : N * (W_ * W_ / 64);                                      \
+    if (want != nchunks) return SALUN_EINVAL;                                                                   \
+    ring_allow_lds(reinterpret_cast<const void *>(conv3x3_wgrad_ring<LOGW_>));                                  \
+    hipLaunchKernelGGL((conv3x3_wgrad_ring<LOGW_>), grid, dim3(256), ldsb, st, a);                              \
+  }
+  switch (W) {
+    case 4: SALUN_WGR(2) break;
+    case 8: SALUN_WGR(3) break;
+    case 16: SALUN_WGR(4) break;
+    case 32: SALUN_WGR(5) break;
+    default: return SALUN_EINVAL;
+  }
+#undef SALUN_WGR
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
 SALUN_EXPORT size_t salun_conv3x3_pack_bytes(int K, int C, int dgrad) {
   const int rows = dgrad ? C : K, red = dgrad ? K : C;
   if (rows <= 0 || red <= 0 || red % RCC != 0) return 0;
@@ -465,6 +728,8 @@ SALUN_EXPORT int salun_conv3x3_packed(const float *x, const float *img, const fl
   if ((long long)N * Cred * H * W >= (1ll << 31) || (long long)N * Kout * H * W >= (1ll << 31)) return SALUN_EINVAL;
   RingArgs a{};
   a.x = x; a.aimg = img; a.bias = bias; a.nbias = nbias; a.addend = addend; a.y = y;
+  a.zero = ring_zero_page();
+  if (!a.zero) return SALUN_EIO;
   a.N = N; a.Cred = Cred; a.H = H; a.Kout = Kout;
   const bool epi = bias || nbias || addend;
   const int wgs = (cfg >> 8) ? (cfg >> 8) : 2;

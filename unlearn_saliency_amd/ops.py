@@ -403,9 +403,11 @@ def conv2d_backward_data(dy: torch.Tensor, w: torch.Tensor, x_shape, stride: int
 
 
 def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: int, pad: int,
-                           out: Optional[torch.Tensor] = None, accumulate: bool = False) -> Optional[torch.Tensor]:
+                           out: Optional[torch.Tensor] = None, accumulate: bool = False,
+                           shared: bool = False) -> Optional[torch.Tensor]:
     """dw = backward_weight(x, dy); with `out` the result is written (accumulate=False) or added
-    (accumulate=True) into that tensor — e.g. the parameter's slice of the flat gradient arena."""
+    (accumulate=True) into that tensor — e.g. the parameter's slice of the flat gradient arena.  `shared`: the launch
+    runs on a side stream beside other kernels of the step (SALUN_WGRAD_SHARED: kernel choice, include/salun.h)."""
     N, C, H, W = x.shape
     K, _, R, _ = w_shape
     P, Q = dy.shape[2], dy.shape[3]
@@ -415,10 +417,11 @@ def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: i
         return None
     ws = workspace(nbytes, x.device)
     dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
-    rc = L.salun_conv2d_backward_weight(_dev(x, torch.float32, "x"), _dev(dy, torch.float32, "dy"),
-                                        _dev(dw, torch.float32, "dw"), N, C, H, W, K, R, stride, pad, P, Q,
-                                        int(bool(accumulate and out is not None)),
-                                        c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream())
+    rc = L.salun_conv2d_backward_weight_ex(_dev(x, torch.float32, "x"), _dev(dy, torch.float32, "dy"),
+                                           _dev(dw, torch.float32, "dw"), N, C, H, W, K, R, stride, pad, P, Q,
+                                           int(bool(accumulate and out is not None)),
+                                           _lib.SALUN_WGRAD_SHARED if shared else 0,
+                                           c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream())
     if rc == _lib.SALUN_EINVAL:
         return None
     check(rc, "salun_conv2d_backward_weight")

@@ -169,7 +169,7 @@ class _BasicBlockFn(FastFunction):
             else:
                 side.wait_stream(main)  # dy (and everything before it) is complete for the side stream
                 with torch.cuda.stream(side):
-                    dw = ops.conv2d_backward_weight(xin, dy, w.shape, stride, pad, out=dst, accumulate=True)
+                    dw = ops.conv2d_backward_weight(xin, dy, w.shape, stride, pad, out=dst, accumulate=True, shared=True)
                 for t in (xin, dy):  # freed when this backward returns: keep the memory until the side stream is done
                     t.record_stream(side)
                 hold_until_join(dy)  # ... and keep autograd from accumulating into it in place meanwhile
@@ -319,7 +319,7 @@ class _DiffusionResnetBlockFn(FastFunction):
             else:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    dw = ops.conv2d_backward_weight(xin, dy, w.shape, 1, pad, out=dst, accumulate=True)
+                    dw = ops.conv2d_backward_weight(xin, dy, w.shape, 1, pad, out=dst, accumulate=True, shared=True)
                 for t in (xin, dy):
                     t.record_stream(side)
                 hold_until_join(dy)

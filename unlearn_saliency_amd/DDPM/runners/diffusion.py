@@ -33,6 +33,7 @@ import torch
 from ... import dist as sdist
 from ... import draws, hostperf, ops
 from ...flat import FlatArena, arena_of
+from ...streams import concurrent_stream
 from ..datasets import data_transform, get_forget_dataset
 from ..functions import cycle, get_optimizer
 from ..functions.losses import loss_registry_conditional, q_sample
@@ -49,7 +50,7 @@ _target_streams: dict = {}
 def _target_stream(device) -> "torch.cuda.Stream":
     s = _target_streams.get(device)
     if s is None:
-        s = _target_streams[device] = torch.cuda.Stream(device=device)
+        s = _target_streams[device] = concurrent_stream(device)
     return s
 
 

@@ -26,6 +26,7 @@ from .. import dist as sdist
 from .. import draws, hostperf, ops
 from ..flat import FlatArena
 from ..optim import FusedMaskedAdam
+from ..streams import concurrent_stream
 from .ldm_lite import SD_V1_FROZEN_PARAMS, LatentDiffusionLite  # noqa: F401 (re-exported)
 from .unet import V1_UNET_CONFIG
 
@@ -153,7 +154,7 @@ def forget_and_target(model, z_noisy, t, c_forget, c_target):
             return out, model.apply_model(z_noisy, t, c_target)
     side = _target_streams.get(dev)
     if side is None:
-        side = _target_streams[dev] = torch.cuda.Stream(device=dev)
+        side = _target_streams[dev] = concurrent_stream(dev)
     main = torch.cuda.current_stream(dev)
     side.wait_stream(main)
     packs = ops.PACK_CALLS[0]

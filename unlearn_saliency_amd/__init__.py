@@ -12,3 +12,11 @@ that path and nothing else.
     Classification / DDPM   host-side mirrors of the reference entry points
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run one after the
+# other.  This package overlaps kernels on side streams (streams.py probes for a queue of their own); more queues make
+# collisions with the communicator's streams rarer.  Read by the HIP runtime when it initialises, i.e. only effective
+# when this import happens before the process first touches the device; never overrides the user's setting.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

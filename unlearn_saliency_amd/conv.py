@@ -91,7 +91,8 @@ class _ConvFn(FastFunction):
             dst = gradsink.sink(ctx.weight_param) if ctx.native else None
             # the weight gradient goes straight into .grad (gradsink): nothing on the main stream consumes it before
             # the end of the backward pass, so it can run on the side stream next to backward-data (resblock.py)
-            overlap = (dst is not None and resblock.OVERLAP_WGRAD and not sdist.collectives_on())
+            # (also under data parallel: the slice's all-reduce waits for the side stream, dist.BucketedGradReducer)
+            overlap = (dst is not None and resblock.OVERLAP_WGRAD)
             if overlap:
                 main, side = torch.cuda.current_stream(dy.device), resblock._side_stream(dy.device)
                 side.wait_stream(main)

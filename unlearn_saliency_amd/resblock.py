@@ -23,7 +23,7 @@ import torch.nn as nn
 import os
 
 from . import dist as sdist
-from . import draws, gradsink, ops
+from . import draws, gradsink, ops, streams
 
 # Backward-weight and backward-data of one convolution depend on the same dY and on nothing of each other.  The
 # backward-weight kernel runs ONE wave per SIMD (register budget) and leaves LDS for a second workgroup, so issuing it
@@ -63,7 +63,7 @@ _side_streams: dict = {}
 def _side_stream(device: torch.device) -> "torch.cuda.Stream":
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
+        s = _side_streams[device] = streams.concurrent_stream(device)
     return s
 
 
@@ -194,9 +194,10 @@ class _BasicBlockFn(FastFunction):
         dw1 = wgrad(x, dc1, w1, s, 1)
         dx = ops.conv2d_backward_data(dc1, w1, x.shape, s, 1, addend=dxd) if ctx.needs_input_grad[0] else None
         if side is not None:
-            if sdist.collectives_on() or not all(g is None for g in (dw1, dw2, dwd)):
-                # data parallel: gradient-arrival hooks may start an all-reduce right after this node; autograd
-                # route: AccumulateGrad consumes the returned tensors on the main stream -> join now
+            if not all(g is None for g in (dw1, dw2, dwd)):
+                # autograd route: AccumulateGrad consumes the returned tensors on the main stream -> join now.
+                # (Data parallel needs no join here any more: a gradient slice's all-reduce waits for the side stream
+                # itself — dist.BucketedGradReducer._launch.)
                 main.wait_stream(side)
                 release_held(dout.device)
             else:
@@ -383,7 +384,7 @@ class _DiffusionResnetBlockFn(FastFunction):
         if gw is not None:
             dg1 = dbt1 = None
         if side is not None:
-            if sdist.collectives_on() or returned:
+            if returned:
                 main.wait_stream(side)
                 release_held(dout.device)
             else:

@@ -1,0 +1,103 @@
+"""Side streams that really run beside the main stream.
+
+HIP maps every stream onto one of a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); two streams on the same
+queue execute strictly one after the other.  Single-process runs got lucky — the current stream and the first
+`torch.cuda.Stream()` landed on different queues — but with a process group the RCCL communicator's own streams shift
+the assignment, and the backward-weight side stream of resblock.py ended up on the MAIN stream's queue: the
+data-parallel ResNet-18 step ran every kernel back to back, 10.03 ms instead of 8.53 (round 6,
+`bench.py --force_collectives`; with GPU_MAX_HW_QUEUES=8 the same run takes 8.66 ms).
+
+`concurrent_stream(device)` therefore PROBES: it keeps the first of a few candidate streams on which a small kernel
+finishes while a few milliseconds of work are still queued on the current stream — and, when a process group over
+RCCL exists, beside which a small all-reduce completes while the candidate is busy.  Under a process group every rank
+probes the SAME number of candidates (the probe's collectives must pair up across ranks whatever each rank finds);
+all ranks create their side streams at the same point of the program.  ~10 - 40 ms, once per side stream.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+_PROBE = os.environ.get("SALUN_STREAM_PROBE", "1") != "0"
+_keep: list = []   # rejected candidates stay alive: torch hands streams out of a pool, a freed one would come back
+STATS = {"probes": 0, "rejected": 0}
+_DP_CANDIDATES = 4  # candidates every rank probes under a process group
+
+
+def _busy(stream, buf, n=24):
+    with torch.cuda.stream(stream):
+        for _ in range(n):          # ~3 ms of streaming passes over 128 MB
+            buf.mul_(1.0)
+
+
+def _beside_main(main, cand, buf, flag) -> bool:
+    main.synchronize()
+    cand.synchronize()
+    e_c = torch.cuda.Event(enable_timing=True)
+    e_m = torch.cuda.Event(enable_timing=True)
+    _busy(main, buf)
+    e_m.record(main)
+    with torch.cuda.stream(cand):
+        flag.add_(1.0)
+        e_c.record(cand)
+    main.synchronize()
+    cand.synchronize()
+    # same hardware queue: the candidate's kernel ran after everything queued on main -> e_c is not before e_m
+    return e_c.elapsed_time(e_m) > 0.5
+
+
+def _beside_collectives(main, cand, buf, probe) -> bool:
+    """Data parallel: the communicator runs its collectives on a stream of its own.  If THAT stream shares the
+    candidate's queue, every backward-weight kernel queued after a gradient slice's all-reduce waits for it — and the
+    all-reduce waits for the main stream to reach the point it was issued at (seen once in round 6: 13.8 ms per step
+    instead of 8.7).  So: with the candidate busy, a small all-reduce issued and awaited from the idle main stream must
+    complete while the candidate is still working."""
+    import torch.distributed as dist
+    main.synchronize()
+    cand.synchronize()
+    e_end = torch.cuda.Event(enable_timing=True)
+    e_coll = torch.cuda.Event(enable_timing=True)
+    _busy(cand, buf)
+    e_end.record(cand)
+    with torch.cuda.stream(main):
+        work = dist.all_reduce(probe, async_op=True)
+        work.wait()
+        e_coll.record(main)
+    main.synchronize()
+    cand.synchronize()
+    return e_coll.elapsed_time(e_end) > 0.5
+
+
+def concurrent_stream(device, tries: int = 8) -> "torch.cuda.Stream":
+    dev = torch.device(device)
+    if not _PROBE or torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream(device=dev)
+    import torch.distributed as dist
+    dp = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    main = torch.cuda.current_stream(dev)
+    with torch.cuda.device(dev):
+        buf = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=dev).zero_()
+        flag = torch.zeros(1, dtype=torch.float32, device=dev)
+        probe = None
+        if dp:
+            probe = torch.zeros(1024, dtype=torch.float32, device=dev)
+            dist.all_reduce(probe)      # communicator set-up, if this is the process group's first collective
+            main.synchronize()
+        first = chosen = None
+        for _ in range(_DP_CANDIDATES if dp else tries):
+            cand = torch.cuda.Stream(device=dev)
+            first = first or cand
+            STATS["probes"] += 1
+            ok = _beside_main(main, cand, buf, flag)
+            if dp:                       # every rank issues this collective for every candidate, accepted or not
+                ok = _beside_collectives(main, cand, buf, probe) and ok
+            if ok and chosen is None:
+                chosen = cand
+                if not dp:
+                    return cand
+            else:
+                STATS["rejected"] += 0 if ok else 1
+                _keep.append(cand)
+        # nothing passed (a one-queue configuration): any stream is as good as another
+        return chosen or first

@@ -97,6 +97,12 @@ def parse():
     ap.add_argument("--no_ddpm", action="store_true",
                     help="skip the CFG-DDPM class-forget block the default one-GPU line carries beside the ResNet-18 "
                          "figures (north_star's second target; `--workload ddpm` is the full-length form)")
+    ap.add_argument("--no_sd", action="store_true",
+                    help="skip the SD-v1 U-Net block (BASELINE configs[4], bf16, batch 8) of the default one-GPU line")
+    ap.add_argument("--sd_steps", type=int, default=4)
+    ap.add_argument("--no_dp", action="store_true",
+                    help="skip the `dp_ws1` figures: the same steps through the data-parallel path (process group over "
+                         "RCCL at world size 1, gradient slices all-reduced behind backward), each in a subprocess")
     ap.add_argument("--ddpm_steps", type=int, default=10)
     ap.add_argument("--ddpm_mask_batches", type=int, default=8,
                     help="forget batches of the embedded DDPM Phase A (the reference's 40 scale linearly)")
@@ -286,6 +292,49 @@ def cpu_baseline(per_gpu_bs, steps, repeats=3):
             "breakdown_ms": {k: 1e3 * v / done for k, v in timers.items()}}
 
 
+def dp_ws1_line(extra, plain_ms):
+    """One workload through the data-parallel path at world size 1 in a subprocess (a process group cannot be created
+    and torn down inside the timed process without disturbing it): the fields that matter of its bench line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force_collectives", "--no_cpu_baseline",
+           "--no_ddpm", "--no_sd", "--no_dp"] + extra
+    env = dict(os.environ)
+    env.setdefault("MASTER_PORT", "29621")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        d = json.loads(lines[-1])
+        out = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "backend", "collectives",
+                                     "rccl_ranks")}
+        out["plain_ms_per_step"] = plain_ms
+        out["dp_over_plain"] = (d["ms_per_step"] / plain_ms) if plain_ms else None
+        out["subprocess_sec"] = time.perf_counter() - t0
+        return out
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def sd_block(a):
+    """`bench.py --workload sd --gpus 1` (bf16, batch 8) in a subprocess; its line's fields that matter."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "sd", "--steps", str(a.sd_steps),
+           "--warmup", "1"] + (["--no_cpu_baseline"] if a.no_cpu_baseline else [])
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        d = json.loads(lines[-1])
+        return {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
+                                  "mask_gen", "roofline", "fwd_bwd", "kernels", "host_enqueue_ms_per_step",
+                                  "cpu_baseline") if k in d}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def selftest_launcher(a):
     """`--gpus N --selftest_launcher`: prove that N ranks were created and can reduce (gloo on a CPU box)."""
     from unlearn_saliency_amd import dist as sdist
@@ -393,7 +442,7 @@ def main():
             + (["--digest"] if a.digest else [])
         if a.workload == "ddpm":
             import bench_ddpm
-            return bench_ddpm.main(argv)
+            return bench_ddpm.main(argv + (["--mask_batches", str(a.ddpm_mask_batches)] if a.no_mask_gen else []))
         import bench_sd
         return bench_sd.main(argv + ["--bf16"])
     rank, local_rank, world = sdist.init_from_env()
@@ -638,6 +687,26 @@ def main():
                                                  "cpu_baseline") if k in d}
             except Exception as exc:  # the headline line must not be lost to the second workload
                 out["ddpm"] = {"error": f"{type(exc).__name__}: {exc}"}
+            if not a.no_sd:
+                # BASELINE configs[4]: the SD-v1 U-Net nsfw_removal step in its bf16 configuration — `--workload sd` in a
+                # process of its own: the step is host-bound (the host needs ~190 of its ~190 ms), and inside THIS
+                # process, behind two other workloads' allocator and interpreter state, it measured 222 ms against 180
+                out["sd"] = sd_block(a)
+            if not a.no_dp:
+                # the data-parallel path at world size 1 (the N > 1 step is not the N = 1 step — other
+                # stream schedule, gradient slices through RCCL): same workloads, short windows, one subprocess each
+                out["dp_ws1"] = {"resnet18": dp_ws1_line(["--steps", "60", "--warmup", "10", "--no_mask_gen"],
+                                                         out["ms_per_step"]),
+                                 "ddpm": dp_ws1_line(["--workload", "ddpm", "--steps", "8", "--warmup", "3",
+                                                      "--no_mask_gen", "--ddpm_mask_batches", "2"],
+                                                     out.get("ddpm", {}).get("ms_per_step")),
+                                 "note": "`bench.py --gpus 1 --force_collectives ...`: process group over RCCL with one "
+                                         "rank, flat-gradient slices all-reduced (AVG) from autograd hooks behind "
+                                         "backward, the fused update waits for them; `plain_ms_per_step` is this "
+                                         "line's single-process figure for the same workload"}
+                if not a.no_sd:
+                    out["dp_ws1"]["sd"] = dp_ws1_line(["--workload", "sd", "--steps", "3", "--warmup", "1"],
+                                                      out.get("sd", {}).get("ms_per_step"))
         print(json.dumps(out), flush=True)
     sdist.barrier()
     if sdist.is_dist():

@@ -40,11 +40,61 @@ def _pmc_adam_traffic():
 FWD_TFLOP_PER_SAMPLE = 0.803  # SURVEY.md §8 D2 (FlopCounterMode on the reference module)
 
 
+def cpu_baseline(batch=1, steps=1):
+    """The reference's nsfw_removal loop body (SD/train-scripts/nsfw_removal.py:60-150; oracle/torch_ref.py sd_unlearn:
+    remain pass + forget pass + pseudo pass, backward, 686x mask multiply, torch.optim.Adam) in plain PyTorch fp32 — the
+    precision the reference script runs in — on this host's cores: `steps` step(s) at batch `batch` on the 859.5 M
+    parameter U-Net after nothing (the one step carries the thread pool's start-up; the sample is bounded: a batch-8
+    step is ~8x the arithmetic).  No activation checkpointing on the CPU (the reference's config enables it; that
+    is a memory device, one extra forward per backward)."""
+    from oracle import torch_ref
+    from unlearn_saliency_amd.SD.unet import UNetModel, V1_UNET_CONFIG
+    torch.manual_seed(0)
+    cfg = dict(V1_UNET_CONFIG)
+    cfg["use_checkpoint"] = False
+    t0 = time.perf_counter()
+    unet = UNetModel(**cfg)
+    with torch.no_grad():
+        for p_ in unet.parameters():   # zero_module layers: give every tensor a gradient path, as the device run does
+            if float(p_.abs().sum()) == 0.0:
+                p_.normal_(0.0, 0.02)
+    ldm = torch_ref.PlainLDM(unet)
+    mask = {n: (torch.rand_like(p_) < 0.5).to(torch.int64) for n, p_ in unet.named_parameters()}
+    t_init = time.perf_counter() - t0
+    mk = lambda *sh: torch.randn(*sh)
+    fb = [(mk(batch, 4, 64, 64), mk(batch, 77, 768), mk(batch, 77, 768)) for _ in range(steps)]
+    rb = [(mk(batch, 4, 64, 64), mk(batch, 77, 768)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    torch_ref.sd_unlearn(ldm, fb, rb, 0.1, 1e-5, mask)
+    dt = time.perf_counter() - t0
+    sps = steps / dt
+    return {"value": sps * batch / 8.0, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "value_at_sampled_batch": sps, "sampled_batch": batch,
+            "sample": f"{steps} nsfw_removal step(s) at batch {batch} (SD-v1 U-Net 859.5 M params fp32, reference op "
+                      f"sequence: 3 forwards, 2 backwards, 686x mask-mul, torch.optim.Adam; no warm-up step, no "
+                      f"checkpointing); `value` = steps/s at the metric's batch 8 assuming time linear in the batch "
+                      f"(x {batch}/8), `value_at_sampled_batch` is what was timed",
+            "ms_per_step_at_sampled_batch": 1e3 * dt / steps, "model_build_sec": t_init,
+            "host_cpu_count": os.cpu_count(), "torch_version": torch.__version__}
+
+
 def main(argv=None):
+    out = run(argv)
+    from unlearn_saliency_amd import dist as sdist
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    sdist.barrier()
+    if sdist.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+def run(argv=None):
+    """-> the result line as a dict on rank 0 (None on the other ranks).  The process group is left to the caller."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--scaling", default="weak", choices=["weak"], help="batch 8 per GPU cannot be split further")
-    ap.add_argument("--no_cpu_baseline", action="store_true", help="accepted for symmetry: this workload has none")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_batch", type=int, default=1, help="batch of the one fp32 reference step timed on the host")
     ap.add_argument("--digest", action="store_true",
                     help="add the SHA-256 of the parameters and the last step's loss to the line (equality tests)")
     ap.add_argument("--steps", type=int, default=3)
@@ -117,7 +167,7 @@ def main(argv=None):
 
     def one_step(z_f, c_f, c_p, z_r, c_r):
         # same body as TS._unlearn with the saliency mask already packed
-        opt = run.opt
+        opt = steps_.opt
         opt.zero_grad()
         remain_loss = model.shared_step({"z": z_r, "c": c_r})[0]
         t = torch.randint(0, model.num_timesteps, (B,), device=dev).long()
@@ -126,27 +176,27 @@ def main(argv=None):
         forget_out, pseudo_out = TS.forget_and_target(model, z_noisy, t, c_f, c_p)
         loss = ops.mse_loss(pseudo_out, forget_out) + 0.1 * remain_loss
         loss.backward()
-        run.last_loss = loss.detach()
+        steps_.last_loss = loss.detach()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         opt.step()
         e1.record()
-        run.tail.append((e0, e1))
+        steps_.tail.append((e0, e1))
         return (loss.detach(),)
 
-    def run(k):
+    def steps_(k):
         model.train()
-        run.tail = []
+        steps_.tail = []
         for (z_f, c_f, c_p), (z_r, c_r) in zip(fdl(k), rdl(k)):
             one_step(z_f, c_f, c_p, z_r, c_r)
-        return run.tail
+        return steps_.tail
 
     from unlearn_saliency_amd.optim import FusedMaskedAdam
-    run.opt = FusedMaskedAdam(arena, lr=1e-5)
-    run.opt.set_mask(m)
+    steps_.opt = FusedMaskedAdam(arena, lr=1e-5)
+    steps_.opt.set_mask(m)
     from unlearn_saliency_amd import hostperf
     hostperf.freeze_gc()  # what the training loops of train_scripts.py do before their first step
-    run(a.warmup)
+    steps_(a.warmup)
     torch.cuda.synchronize()
     sdist.barrier()
     if os.environ.get("SALUN_SYNC_DEBUG"):  # diagnostics: warn on every host-synchronising call inside the timed steps
@@ -155,7 +205,7 @@ def main(argv=None):
     gc.collect()
     gc.disable()  # no collector pause inside the timed steps (re-enabled below)
     t0 = time.perf_counter()
-    tail = run(a.steps)
+    tail = steps_(a.steps)
     host_enqueue_s = time.perf_counter() - t0  # the host has issued every step; the device may still be running
     torch.cuda.synchronize()
     sdist.barrier()
@@ -201,13 +251,15 @@ def main(argv=None):
     if a.digest:
         import hashlib
         out["params_sha256"] = hashlib.sha256(arena.params.cpu().numpy().tobytes()).hexdigest()
-        out["last_loss"] = float(run.last_loss)
-        out["collectives"] = bool(sdist.collectives_on())
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    sdist.barrier()
-    if sdist.is_dist():
-        torch.distributed.destroy_process_group()
+        out["last_loss"] = float(steps_.last_loss)
+    out["collectives"] = bool(sdist.collectives_on())
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        del model, arena, m
+        steps_.opt = None
+        torch.cuda.empty_cache()
+        with contextlib.redirect_stdout(sys.stderr):
+            out["cpu_baseline"] = cpu_baseline(a.cpu_batch, 1)
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ DDPM = [
 ]
 
 
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=60, warm=120):  # sustained clock: see tools/convring_bench.py
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

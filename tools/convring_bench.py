@@ -13,7 +13,10 @@ DDPM = [("128->128 @32", 128, 128, 32, 128), ("256->256 @16", 128, 256, 16, 256)
         ("256->256 @8", 128, 256, 8, 256), ("256->256 @4", 128, 256, 4, 256)]
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=100, warm=150):
+    # 150 warm-up launches (> 20 ms): the chip takes 15 - 20 ms of continuous work to reach its sustained clock (blocks of
+    # 100 launches of one kernel: 167, 150, 145, 145, ... us — tools/sustained_bench.py); a 3-launch warm-up made the
+    # first variant timed after an idle spell look 9 - 13 % slower than the same kernel timed later (round 6)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

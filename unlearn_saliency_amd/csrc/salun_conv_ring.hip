@@ -239,7 +239,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
         for (int v = 0; v < 16; ++v) acc[pt][t][v] = 0.f;
 
     for (int ch = 0; ch < nchunk; ++ch) {
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the chunk (requested a whole chunk ago) is in LDS
+      // vmcnt(0): this wave's share of the chunk (requested a whole chunk ago) is in LDS.  Not at the first chunk of a
+      // later tile: its DMA was waited for BEFORE the previous tile's output stores were issued (below) — a wait here
+      // would also drain those 16 .. 64 stores per lane, a few microseconds per tile with nothing to hide them behind
+      // (both workgroups of a CU reach their epilogues together).
+      if (ch > 0 || tile == (int)blockIdx.x) __builtin_amdgcn_s_waitcnt(0x0f70);
       __builtin_amdgcn_s_barrier();        // ... everyone's is, and everyone has finished reading the other stage
       if (it_tile < total) {
         issue(it_chunk, stage ^ 1);
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
     }
 
     // ---- epilogue: D[row = channel][col = pixel]; row = (v & 3) + 8 * (v >> 2) + 4 * hi
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // the next tile's first chunk (in flight since the last barrier) has landed
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int n_out = n_l[pt], p_out = p0 + p_l[pt];

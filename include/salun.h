@@ -53,6 +53,10 @@ int salun_version(void);
 const char *salun_strerror(int code);
 /* Target ISA the kernels were compiled for ("gfx950"). */
 const char *salun_arch(void);
+/* Measurement tooling (tools/clock_probe.py): one wave samples the shader-cycle counter against the 100 MHz constant
+ * counter `samples` times, `spins` s_sleep(127) apart: out[2i] = shader cycles, out[2i+1] = 100 MHz ticks.  Launched on a
+ * stream of its own beside a workload it reads the clock the chip sustains under that workload. */
+int salun_clock_probe(unsigned long long *out /*dev, 2*samples*/, int samples, int spins, salun_stream_t stream);
 
 /* ------------------------------------------------------------------ K1 --
  * Saliency accumulation:   acc[i] <- acc[i] + (g[i] * scale)      (2 roundings)

@@ -55,6 +55,7 @@ SIGNATURES = {
     "salun_version": (c_int, []),
     "salun_strerror": (ctypes.c_char_p, [c_int]),
     "salun_arch": (ctypes.c_char_p, []),
+    "salun_clock_probe": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "salun_saliency_accumulate": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_double, c_int64, c_void_p]),
     "salun_mask_topk_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "salun_mask_topk": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_int64), c_int, ctypes.POINTER(c_void_p),

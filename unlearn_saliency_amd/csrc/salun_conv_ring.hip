@@ -133,8 +133,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
   const int lo = lane & 31, hi = lane >> 5;
   const int wp = wave % WP, wk = wave / WP;
   const int H = g.H, TP = g.TP, NI = g.NI, N = g.N, Cred = g.Cred;
-  const int PRI = TP + 2;               // patch rows per image
-  const int PSZ = NI * PRI * W;         // patch floats per channel
+  const int PRI = TP + 2;               // patch rows per image that carry data
+  // rows per image in LDS: a 32-lane operand read of 4-wide images covers TWO images (16 pixels each); with the
+  // images 6 rows = 24 floats apart, lanes 16-31 fall on the banks of lanes 0-7 (2-way, 40 % of the LDS cycles of the
+  // 512-channel layers: profiles/r06_conv_sq_*); 12 rows = 48 floats apart they take banks 16-31
+  const int IRS = (W == 4 && NI > 1) ? 12 : PRI;
+  const int PSZ = NI * IRS * W;         // patch floats per channel
   const int PSZ4 = PSZ / 4;
   const int npiece = RCC * PSZ4;        // 16-byte pieces of a patch chunk
   const int P_BYTES = ((npiece + 63) / 64) * 1024;
@@ -159,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
       const int e = (wave + 4 * j) * 64 + lane;
       const int c = e / PSZ4, jj = e - c * PSZ4;
       const int row = jj >> (LOGW - 2), col4 = jj & (W4 - 1);
-      const int ni = row / PRI, rr = row - ni * PRI;
+      const int ni = row / IRS, rr = row - ni * IRS;
       const int ih = p0 - 1 + rr, n = n0 + ni;
-      const bool act = e < npiece;
+      const bool act = e < npiece && rr < PRI;   // (rows PRI .. IRS-1 are spacing: never written, never read)
       const bool valid = act && n < N && ih >= 0 && ih < H;
       pact[j] = act;
       psrc[j] = valid ? g.x + ((size_t)(n * Cred + c) * H + ih) * W + 4 * col4 : g.zero + 4 * lane;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
       p_l[pt] = pr - ni * TP;
       n_l[pt] = n0 + ni;
       // byte offset of tap (r = 0, s = 0) of this pixel in channel `hi` of the patch (patch row 0 = image row p0 - 1)
-      boff[pt] = ((hi * PSZ) + (ni * PRI + p_l[pt]) * W + q_l[pt] - 1) * 4;
+      boff[pt] = ((hi * PSZ) + (ni * IRS + p_l[pt]) * W + q_l[pt] - 1) * 4;
       okL[pt] = q_l[pt] != 0;
       okR[pt] = q_l[pt] != W - 1;
     }
@@ -369,9 +373,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_ring(const RingArgs g) {
 //     read.  The reduction index of an MFMA step is a pixel, so any pairing works as long as A and B agree: half `hi`
 //     of the wave takes pixels 8m + 4hi + e at step 4m + e;
 //   * the nine taps of those four pixels need, per patch row, the pixels q0-1 .. q0+4: one aligned ds_read_b128 plus the
-//     two neighbours as ds_read_b32 (zero where the neighbour is outside the image row: a compile-time property of
-//     (m, hi), applied with one v_cndmask).  The B operand of tap (r, s) at step e is then simply register e + s of
-//     that row's six: 10 LDS reads per 36 MFMAs where conv_wgrad_v issues 40.
+//     two neighbours from the adjacent aligned pieces (zero where the neighbour is outside the image row: a compile-time
+//     property of (m, hi), applied with one v_cndmask).  The B operand of tap (r, s) at step e is then simply register
+//     e + s of that row's six: 10 conflict-free LDS reads per 36 MFMAs where conv_wgrad_v issues 40.
 // Summation order over the pixels differs from conv_wgrad_v's (same exact-fp32 FMA chains, other pairing).
 struct WgradRingArgs {
   const float *x;     // [N][C][H][W]
@@ -487,8 +491,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_ring(const WgradRingArgs g)
         Row o;
         o.v = *reinterpret_cast<const float4 *>(B + off);
         if (W > 4) {
-          o.l = *reinterpret_cast<const float *>(B + off - 4);
-          o.r = *reinterpret_cast<const float *>(B + off + 16);
+          // the neighbours as the last / first element of the ADJACENT aligned pieces: a dword read at a row stride of
+          // 4 x odd floats is a 4-way bank conflict (64 % of this kernel's LDS cycles in the first build:
+          // profiles/r06_conv_sq_*), the 16-byte read is conflict-free like the operand's own
+          // (volatile: hipcc narrows a 16-byte load of which one element is used back to the conflicting dword read)
+          typedef float f32x4v __attribute__((ext_vector_type(4)));
+          typedef const volatile __attribute__((address_space(3))) f32x4v *lds_v4_t;  // (explicitly LDS: a volatile
+          const f32x4v lv = *(lds_v4_t)(ring_lds_ptr_t)(B + off - 16);                 //  generic pointer loads flat)
+          const f32x4v rv = *(lds_v4_t)(ring_lds_ptr_t)(B + off + 16);
+          o.l = lv.w;
+          o.r = rv.x;
         } else {
           o.l = 0.f;
           o.r = 0.f;
@@ -628,7 +640,8 @@ int ring_launch(RingArgs a, int W, bool epi, int wgs_per_cu, hipStream_t st) {
   a.ntile_k = (a.Kout + KB - 1) / KB;
   a.ntiles = ptiles * a.ntile_k;
   a.nchunk = a.Cred / RCC;
-  const int PSZ = a.NI * (a.TP + 2) * W;
+  const int IRS = (W == 4 && a.NI > 1) ? 12 : a.TP + 2;  // rows per image in LDS (the kernel's IRS)
+  const int PSZ = a.NI * IRS * W;
   const int npiece = RCC * PSZ / 4;
   if (npiece > 12 * 64) return SALUN_EINVAL;  // NPW = 3 units per wave
   const size_t stage = (size_t)(WK * KT) * RGROUPS * 1024 + (size_t)((npiece + 63) / 64) * 1024;

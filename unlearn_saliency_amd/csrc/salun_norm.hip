@@ -16,6 +16,26 @@ namespace {
 
 constexpr int BN_MAX_SPLIT = 64;
 
+// Walk of the float4 items e = tid, tid + 256, ... of a (channel, batch slice): image n = n_lo + e / hw4, piece
+// i = e % hw4 — advanced WITHOUT a division per item.  Round 6: these kernels run beside the backward-weight kernel of
+// the side stream, whose MFMA stream leaves other waves of its SIMD few VALU issue slots (BatchNorm backward took
+// 118 - 147 us there against 79 us alone); the integer division was the longest dependent VALU chain of every iteration.
+struct BnWalk {
+  int n, i, dn, di, hw4;
+  __device__ __forceinline__ BnWalk(int n_lo, int hw4_) : hw4(hw4_) {
+    const int t = threadIdx.x;
+    n = n_lo + t / hw4_;
+    i = t - (t / hw4_) * hw4_;
+    dn = 256 / hw4_;
+    di = 256 - dn * hw4_;
+  }
+  __device__ __forceinline__ void next() {
+    n += dn;
+    i += di;
+    if (i >= hw4) { i -= hw4; ++n; }
+  }
+};
+
 // partial[(c*nsplit + s)*2 + {0,1}]: sums over images n in slice s of channel c
 __global__ __launch_bounds__(256) void k_bn_stats_partial(const float *__restrict__ x, int N, int C, int HW, int nsplit,
                                                           double *__restrict__ partial) {
@@ -27,8 +47,10 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float *__restric
   const int hw4 = HW >> 2;
   const int work = (n_hi - n_lo) * hw4;  // float4 items of this (channel, slice): all lanes busy even for 4x4 maps
   int it = 0;
-  for (int e = threadIdx.x; e < work; e += 256, ++it) {
-    const int n = n_lo + e / hw4, i = e - (e / hw4) * hw4;
+  BnWalk wk(n_lo, hw4);
+#pragma unroll 2
+  for (int e = threadIdx.x; e < work; e += 256, ++it, wk.next()) {
+    const int n = wk.n, i = wk.i;
     const float4 v = reinterpret_cast<const float4 *>(x + ((size_t)n * C + c) * HW)[i];
     s1 += (v.x + v.y) + (v.z + v.w);
     s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -107,8 +129,10 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, c
   const int n_lo = (int)((int64_t)N * s / nsplit), n_hi = (int)((int64_t)N * (s + 1) / nsplit);
   const int hw4 = HW >> 2;
   const int work = (n_hi - n_lo) * hw4;
-  for (int e = threadIdx.x; e < work; e += 256) {
-    const int n = n_lo + e / hw4, i = e - (e / hw4) * hw4;
+  BnWalk wk(n_lo, hw4);
+#pragma unroll 2
+  for (int e = threadIdx.x; e < work; e += 256, wk.next()) {
+    const int n = wk.n, i = wk.i;
     const size_t off = ((size_t)n * C + c) * HW;
     const float4 v = reinterpret_cast<const float4 *>(x + off)[i];
     float4 o;
@@ -140,8 +164,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict_
   const int hw4 = HW >> 2;
   const int work = (n_hi - n_lo) * hw4;
   int it = 0;
-  for (int e = threadIdx.x; e < work; e += 256, ++it) {
-    const int n = n_lo + e / hw4, i = e - (e / hw4) * hw4;
+  BnWalk wk(n_lo, hw4);
+#pragma unroll 2
+  for (int e = threadIdx.x; e < work; e += 256, ++it, wk.next()) {
+    const int n = wk.n, i = wk.i;
     const size_t off = ((size_t)n * C + c) * HW;
     float4 g = reinterpret_cast<const float4 *>(dy + off)[i];
     const float4 xv = reinterpret_cast<const float4 *>(x + off)[i];
@@ -203,8 +229,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
   const int n_lo = (int)((int64_t)N * s / nsplit), n_hi = (int)((int64_t)N * (s + 1) / nsplit);
   const int hw4 = HW >> 2;
   const int work = (n_hi - n_lo) * hw4;
-  for (int e = threadIdx.x; e < work; e += 256) {
-    const int n = n_lo + e / hw4, i = e - (e / hw4) * hw4;
+  BnWalk wk(n_lo, hw4);
+#pragma unroll 2
+  for (int e = threadIdx.x; e < work; e += 256, wk.next()) {
+    const int n = wk.n, i = wk.i;
     const size_t off = ((size_t)n * C + c) * HW;
     float4 g = reinterpret_cast<const float4 *>(dy + off)[i];
     if (RELU) {

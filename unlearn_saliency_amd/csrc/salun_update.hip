@@ -527,3 +527,28 @@ SALUN_EXPORT int salun_fim_square_accumulate(float *F, float *tmp, double n_data
   SALUN_LAUNCH_CHECK();
   return SALUN_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// Shader-clock probe (measurement tooling: tools/clock_probe.py).  One wave reads the shader-cycle counter (s_memtime)
+// and the 100 MHz constant counter (s_memrealtime) `spins` sleeps apart: out[2i] = shader cycles, out[2i+1] = 100 MHz
+// ticks of sample i — their ratio x 100 MHz is the clock the chip actually ran at while whatever else was resident ran.
+namespace {
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *__restrict__ out, int samples, int spins) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < samples; ++i) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int k = 0; k < spins; ++k) __builtin_amdgcn_s_sleep(127);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[2 * i] = t1 - t0;
+    out[2 * i + 1] = r1 - r0;
+  }
+}
+}  // namespace
+
+SALUN_EXPORT int salun_clock_probe(unsigned long long *out, int samples, int spins, salun_stream_t stream) {
+  if (!out || samples < 1 || spins < 1) return SALUN_EINVAL;
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, salun_hip_stream(stream), out, samples, spins);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}

@@ -16,6 +16,10 @@ namespace {
 
 constexpr int BN_MAX_SPLIT = 64;
 
+// (Round 6, measured and NOT adopted: s_setprio 1 / 3 in these kernels.  Beside the backward-weight kernel they got faster
+// — BatchNorm backward 128 -> 96 us — but the training step got 2.7 % slower: the side stream's backward-weight chain is
+// the critical path of backward and loses what these kernels win.  Same sign as priorities on the matrix kernels.)
+
 // Walk of the float4 items e = tid, tid + 256, ... of a (channel, batch slice): image n = n_lo + e / hw4, piece
 // i = e % hw4 — advanced WITHOUT a division per item.  Round 6: these kernels run beside the backward-weight kernel of
 // the side stream, whose MFMA stream leaves other waves of its SIMD few VALU issue slots (BatchNorm backward took

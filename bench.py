@@ -590,7 +590,7 @@ def main():
     fb_mean_s = 1e-3 * sum(fb_ms) / max(len(fb_ms), 1)
     pmc_traffic, pmc_src = None, None
     try:  # HBM bytes per launch: a CONSTANT read from the committed PMC passes, not measured in this run
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             pth = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
             if os.path.exists(pth):
                 with open(pth) as f:

@@ -129,10 +129,13 @@ def test_side_stream_backward_weight_never_changes_a_gradient_bit():
     e, t = torch.randn_like(x), torch.randint(0, 1000, (128,), device="cuda")
     b = torch.linspace(1e-4, 0.02, 1000, device="cuda")
 
+    from unlearn_saliency_amd import ops
+
     def grads(overlap):
         prev = resblock.OVERLAP_WGRAD
         resblock.OVERLAP_WGRAD = overlap
-        try:
+        ops.WGRAD_KERNEL[0] = "shared"   # the same backward-weight kernel on either schedule (round 6: a launch that does
+        try:                             # not share the device takes the ring kernel — another summation order)
             torch.manual_seed(5)  # label drop
             from unlearn_saliency_amd import draws
             draws.set_state((5, 1, 0))  # dropout keys
@@ -141,6 +144,7 @@ def test_side_stream_backward_weight_never_changes_a_gradient_bit():
             torch.cuda.synchronize()
         finally:
             resblock.OVERLAP_WGRAD = prev
+            ops.WGRAD_KERNEL[0] = None
         return arena.grads.clone()
 
     ref = grads(False)

@@ -99,7 +99,7 @@ def pmc_tail_traffic():
     """HBM bytes of the optimizer tail (salun_grad_sqnorm + salun_masked_adam_step at N_D) from the committed PMC passes:
     a CONSTANT (counters cannot be collected inside a timed run), labelled as such."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         pth = os.path.join(root, "profiles", f"{rnd}_pmc_traffic.json")
         if not os.path.exists(pth):
             continue

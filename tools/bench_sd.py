@@ -26,7 +26,7 @@ def _pmc_adam_traffic():
     """HBM bytes of one salun_masked_adam_step launch at N_S from the committed PMC passes: a CONSTANT (counters cannot be
     collected inside a timed run), labelled as such."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for rnd in ("r05", "r04", "r02"):
+    for rnd in ("r06", "r05", "r04", "r02"):
         pth = os.path.join(root, "profiles", f"{rnd}_pmc_traffic.json")
         try:
             with open(pth) as f:

@@ -402,6 +402,11 @@ def conv2d_backward_data(dy: torch.Tensor, w: torch.Tensor, x_shape, stride: int
     return dx
 
 
+# None: the caller's `shared` flag decides the 3x3 / stride 1 backward-weight kernel; "shared" / "alone" pin one (tests that
+# compare a side-stream schedule with the single-stream one bit for bit need the same kernel in both)
+WGRAD_KERNEL = [None]
+
+
 def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: int, pad: int,
                            out: Optional[torch.Tensor] = None, accumulate: bool = False,
                            shared: bool = False) -> Optional[torch.Tensor]:
@@ -420,7 +425,8 @@ def conv2d_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: i
     rc = L.salun_conv2d_backward_weight_ex(_dev(x, torch.float32, "x"), _dev(dy, torch.float32, "dy"),
                                            _dev(dw, torch.float32, "dw"), N, C, H, W, K, R, stride, pad, P, Q,
                                            int(bool(accumulate and out is not None)),
-                                           _lib.SALUN_WGRAD_SHARED if shared else 0,
+                                           _lib.SALUN_WGRAD_SHARED if (shared if WGRAD_KERNEL[0] is None
+                                                                       else WGRAD_KERNEL[0] == "shared") else 0,
                                            c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream())
     if rc == _lib.SALUN_EINVAL:
         return None

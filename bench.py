@@ -207,7 +207,9 @@ def time_mask_gen(model, forget_loader, criterion):
     torch.cuda.synchronize()
     dev_us = sorted(1e3 * a.elapsed_time(b) for a, b in ev)
     zeros = int((acc == 0).sum().item())
-    return masks[0.5], {"total_sec": saliency_sec + (t2 - t1), "saliency_sec": saliency_sec,
+    keep = masks[0.5].clone()  # the ten masks are rows of ONE allocation: a clone lets the other nine (100 MB) go
+    masks = outs = None
+    return keep, {"total_sec": saliency_sec + (t2 - t1), "saliency_sec": saliency_sec,
                         "topk_10_thresholds_sec": t2 - t1, "topk_10_thresholds_first_call_sec": first_call,
                         "topk_route": route, "topk_error": err,
                         "topk_10_thresholds_device_us": dev_us[len(dev_us) // 2],

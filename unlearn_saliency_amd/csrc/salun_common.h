@@ -34,13 +34,16 @@ static inline int salun_grid_for(int64_t work_items, int per_block) {
 static inline int salun_device_bit() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
-  return dev & 63;
+  return dev & 63;  // (one node holds 8 devices; ids >= 64 would alias — the flags below are "set an attribute once", benign)
 }
-static inline bool salun_once_per_device(unsigned long long *done) {  // true the first time on this device
-  const int b = salun_device_bit();
-  if ((*done >> b) & 1ull) return false;
-  *done |= 1ull << b;
-  return true;
+// "Done once per device" flags (dynamic-LDS opt-ins): one bit per device, read and published atomically (one host
+// thread per GPU makes a plain read-modify-write a data race).  The bit is published AFTER the work, so a racing thread
+// either repeats the (idempotent) attribute call or sees it done — never launches ahead of it.
+static inline bool salun_once_needed(const unsigned long long *done) {
+  return ((__atomic_load_n(done, __ATOMIC_ACQUIRE) >> salun_device_bit()) & 1ull) == 0;
+}
+static inline void salun_once_mark(unsigned long long *done) {
+  (void)__atomic_fetch_or(done, 1ull << salun_device_bit(), __ATOMIC_RELEASE);
 }
 
 static inline bool salun_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -743,6 +743,8 @@ int wgrad_splits(int tiles, int chunks) {
   return s;
 }
 
+// (The kernels lean on this domain: aim_tap's `tap / 3` as (tap * 11) >> 5 is exact for tap < 9 only, i.e. R in {1, 3}, and
+// the backward-weight epilogue guards whole waves with K % 32 == 0.  Widening it means revisiting both — ADVICE r5.)
 bool supported(int C, int K, int R, int stride, int pad) {
   return (R == 1 || R == 3) && (stride == 1 || stride == 2) && pad >= 0 && pad <= R - 1 && C % 32 == 0 && K % 32 == 0 &&
          C >= 32 && K >= 32;
@@ -771,11 +773,11 @@ int launch_igemm(IgArgs a, void *ws, size_t ws_bytes, hipStream_t st) {
   constexpr int B_BYTES = BTR ? (BN / 32) * (BK * 64) : BN * ROWB;
   const size_t lds = 2 * (size_t)(A_BYTES + B_BYTES);
   static unsigned long long attr_done = 0;  // one bit per device
-  if (!((attr_done >> salun_device_bit()) & 1ull)) {
+  if (salun_once_needed(&attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_igemm<WM, WN, BK, BTR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SALUN_EIO;
-    attr_done |= 1ull << salun_device_bit();
+    salun_once_mark(&attr_done);
   }
   const int mt = (a.M + BM - 1) / BM, nt = (a.Kout + BN - 1) / BN;
   const int nstage = a.R * a.R * (a.Cin / BK);
@@ -821,11 +823,11 @@ int launch_wgrad(const WgArgs &a, int splits, hipStream_t st) {
   constexpr int PW = 7 * ST + R;
   const size_t lds = 2 * (size_t)(2 * 64 * 64 + 2 * PW * PW * 64);
   static unsigned long long attr_done = 0;  // one bit per device
-  if (!((attr_done >> salun_device_bit()) & 1ull)) {
+  if (salun_once_needed(&attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_wgrad<R, ST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SALUN_EIO;
-    attr_done |= 1ull << salun_device_bit();
+    salun_once_mark(&attr_done);
   }
   WgArgs b = a;
   {  // buffer descriptors: an out-of-image lane reads at byte offset 2^31, which must lie past the end of both tensors

@@ -1049,11 +1049,10 @@ int launch_gemm_bf16_r(const GbArgs &g0, hipStream_t st) {
   g.tiles_n = g.N / BNt;
   const size_t ldsb = (size_t)NST * (BMt + BNt) * BK * 2;
   static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
-  const int cfg_dev = salun_device_bit();
-  if (!((configured >> cfg_dev) & 1ull)) {
+  if (salun_once_needed(&configured)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt_r<WGM, WGN, NST, BK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured |= 1ull << cfg_dev;
+    salun_once_mark(&configured);
   }
   hipLaunchKernelGGL((k_gemm_bf16_nt_r<WGM, WGN, NST, BK>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
@@ -1292,11 +1291,10 @@ int launch_conv_ring(const IrArgs &g0, hipStream_t st) {
   g.tiles_n = g.Kout / BNt;
   const size_t ldsb = (size_t)NST * (BMt + BNt) * 64;
   static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
-  const int cfg_dev = salun_device_bit();
-  if (!((configured >> cfg_dev) & 1ull)) {
+  if (salun_once_needed(&configured)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_bf16_ring<WGM, WGN, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured |= 1ull << cfg_dev;
+    salun_once_mark(&configured);
   }
   hipLaunchKernelGGL((k_conv_bf16_ring<WGM, WGN, NST>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
@@ -1551,11 +1549,10 @@ template <int WGA, int WGB, int RST, int NST>
 int launch_gemm_bf16_tn(const TnArgs &g, int splits, hipStream_t st) {
   const size_t ldsb = (size_t)NST * (64 * WGA + 64 * WGB) / 32 * RST * 64;
   static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
-  const int cfg_dev = salun_device_bit();
-  if (!((configured >> cfg_dev) & 1ull)) {
+  if (salun_once_needed(&configured)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_tn<WGA, WGB, RST, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured |= 1ull << cfg_dev;
+    salun_once_mark(&configured);
   }
   hipLaunchKernelGGL((k_gemm_bf16_tn<WGA, WGB, RST, NST>), dim3(g.tiles_a * g.tiles_b * splits), dim3(64 * WGA * WGB), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
@@ -1598,11 +1595,10 @@ int launch_gemm_bf16(const GbArgs &g0, hipStream_t st) {
   g.tiles_n = g.N / BNt;
   const size_t ldsb = (size_t)(DB ? 2 : 1) * (BMt + BNt) * 128;
   static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
-  const int cfg_dev = salun_device_bit();
-  if (!((configured >> cfg_dev) & 1ull)) {
+  if (salun_once_needed(&configured)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt<WGM, WGN, DB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured |= 1ull << cfg_dev;
+    salun_once_mark(&configured);
   }
   hipLaunchKernelGGL((k_gemm_bf16_nt<WGM, WGN, DB>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), ldsb, st, g);
   SALUN_LAUNCH_CHECK();
@@ -1617,11 +1613,10 @@ int launch_gemm_bf16_p(const GbArgs &g0, hipStream_t st) {
   g.tiles_n = g.N / BNt;
   const size_t ldsb = (size_t)2 * (BMt + BNt) * 128;
   static unsigned long long configured = 0;  // one bit per device: the opt-in is per device, not per process
-  const int cfg_dev = salun_device_bit();
-  if (!((configured >> cfg_dev) & 1ull)) {
+  if (salun_once_needed(&configured)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_bf16_nt_p<WGM, WGN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    configured |= 1ull << cfg_dev;
+    salun_once_mark(&configured);
   }
   const int ntile = g.tiles_m * g.tiles_n;
   // 2 workgroups per CU (LDS: 2 x 64-80 KB); each walks a run of tiles inside its XCD's contiguous range

@@ -1102,7 +1102,10 @@ __global__ __launch_bounds__(1024) void k_finish(FastState *fs, TopkPub *pub, co
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have left
       __syncthreads();
       if (tid == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(&fs->fin_ticket[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // acquire-release at agent scope: the write-through stores + drained vmcnt above and the sc1 loads
+        // below are the hand-off that works on gfx950 (cdna_hip_programming.md G16, form R1); the ordering on the
+        // ticket is what the HIP memory model needs to say the same thing — ~2 us on a call of 80 us or more
+        const uint32_t t = __hip_atomic_fetch_add(&fs->fin_ticket[j], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == (uint32_t)(F - 1)) ? 1u : 0u;
       }
       __syncthreads();
@@ -1807,7 +1810,7 @@ inline WsLayout ws_layout(int64_t n, int nk) {
 int g_cu_count = 0;
 unsigned long long g_fullscan_attr = 0;  // one bit per device: the dynamic-LDS opt-in is per device
 inline int fullscan_grid(int64_t n) {
-  if (salun_once_per_device(&g_fullscan_attr)) {
+  if (salun_once_needed(&g_fullscan_attr)) {
     // 2 KiB + 16 x 4 KiB of dynamic LDS at the maximum threshold count: above the 64 KiB default
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fullscan), hipFuncAttributeMaxDynamicSharedMemorySize,
                               96 * 1024);
@@ -1817,6 +1820,7 @@ inline int fullscan_grid(int64_t n) {
       g_cu_count = cus;   // (devices of one node are the same part)
     else if (g_cu_count == 0)
       g_cu_count = 64;
+    salun_once_mark(&g_fullscan_attr);
   }
   int64_t g = 2 * (int64_t)g_cu_count;  // resident with room to spare: the grid barrier needs every workgroup running
   if (g > 512) g = 512;

@@ -108,7 +108,10 @@ def mask_topk(acc: torch.Tensor, ks: Sequence[int], out: Optional[Sequence[torch
         out, marr = [], None
     else:
         if out is None:  # one allocation for all thresholds: the masks are rows of it, each row 256-byte aligned (the
-            # single-read route stores the masks as dwords)
+            # single-read route stores the masks as dwords).  NOTE: the nk masks SHARE that storage — keeping
+            # one keeps all nk * n bytes resident, and pickling a row serialises the whole block; callers that keep a
+            # subset for long (the unlearning loops keep one ratio) should `.clone()` it, the save paths already go
+            # through unpack_mask, which copies
             n_pad = (n + 255) & ~255
             out = [r[:n] for r in torch.empty((nk, n_pad), dtype=torch.uint8, device=acc.device).unbind(0)]
         assert len(out) == nk and all(o.numel() == n for o in out)

@@ -1825,6 +1825,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_scalar(const float *__r
 
 inline void launch_wgrad_reduce(const float *part, float *dw, int64_t n, int nsplit, int accumulate, int KC, int RS,
                                 hipStream_t st) {
+#ifdef SALUN_WGRAD_EXP_NOFOLD  // lab builds only (results WRONG): what the step costs without the folds in backward
+  if (n > 0) return;
+#endif
   if ((n & 3) || !salun_aligned16(part)) {
     hipLaunchKernelGGL(conv_wgrad_reduce_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, dw, n,
                        nsplit, accumulate, KC, RS);

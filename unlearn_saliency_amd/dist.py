@@ -62,6 +62,11 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
         dist.init_process_group(backend=backend, rank=rk, world_size=ws, **kw)
+        if backend == "nccl":
+            # side streams (backward-weight, the diffusion steps' target pass, the collectives' launch stream) probed NOW, on every rank at the same
+            # point, because their probe includes collectives (streams.py)
+            from . import streams
+            streams.prepare(kw["device_id"], 3)
     return rk, lrk, ws
 
 
@@ -245,7 +250,11 @@ class BucketedGradReducer:
             else:
                 aux = self._aux.get(dev)
                 if aux is None:
-                    aux = self._aux[dev] = torch.cuda.Stream(device=dev)
+                    # a stream with a hardware queue of its own, like the side streams: on the compute stream's queue
+                    # its wait for the side stream would hold back every later kernel of the compute stream (seen:
+                    # 9.9 instead of 8.7 ms per step)
+                    from . import streams
+                    aux = self._aux[dev] = streams.concurrent_stream(dev)
                 aux.wait_stream(torch.cuda.current_stream(dev))
                 aux.wait_stream(side)
                 with torch.cuda.stream(aux):

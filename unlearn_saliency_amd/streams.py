@@ -9,9 +9,11 @@ data-parallel ResNet-18 step ran every kernel back to back, 10.03 ms instead of 
 
 `concurrent_stream(device)` therefore PROBES: it keeps the first of a few candidate streams on which a small kernel
 finishes while a few milliseconds of work are still queued on the current stream — and, when a process group over
-RCCL exists, beside which a small all-reduce completes while the candidate is busy.  Under a process group every rank
-probes the SAME number of candidates (the probe's collectives must pair up across ranks whatever each rank finds);
-all ranks create their side streams at the same point of the program.  ~10 - 40 ms, once per side stream.
+RCCL exists, beside which a small all-reduce completes while the candidate is busy.  The collectives of that probe must
+pair up across ranks, so they are issued only from `prepare()`, which `dist.init_from_env` calls on every rank right after
+it created the process group (every rank probes the SAME number of candidates whatever each finds) and which stocks a
+small pool; `concurrent_stream()` hands out the pool first and otherwise probes WITHOUT collectives — a rank that skips a
+backward pass (empty shard) must not leave the others waiting in one.  ~10 - 40 ms per stream, once.
 """
 from __future__ import annotations
 
@@ -72,12 +74,40 @@ def _beside_collectives(main, cand, buf, probe) -> bool:
     return e_coll.elapsed_time(e_end) > 0.5
 
 
+_pool: dict = {}      # device -> streams probed by prepare() (incl. against the communicator) and not handed out yet
+
+
+def prepare(device, count: int = 2) -> None:
+    """Called by every rank at the same point (dist.init_from_env, after the process group exists): probe `count` side
+    streams including the collective part and keep them for `concurrent_stream`."""
+    dev = torch.device(device)
+    if not _PROBE or not torch.cuda.is_available():
+        return
+    for _ in range(count):
+        _pool.setdefault(dev, []).append(_probe(dev, 8, True))
+
+
 def concurrent_stream(device, tries: int = 8) -> "torch.cuda.Stream":
     dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     if not _PROBE or torch.cuda.is_current_stream_capturing():
         return torch.cuda.Stream(device=dev)
+    if _pool.get(dev):
+        st = _pool[dev].pop(0)
+        if os.environ.get("SALUN_STREAM_DEBUG"):
+            import sys
+            buf = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=dev).zero_()
+            flag = torch.zeros(1, dtype=torch.float32, device=dev)
+            print("streams: pooled stream beside the current stream at hand-out:",
+                  _beside_main(torch.cuda.current_stream(dev), st, buf, flag), file=sys.stderr)
+        return st
+    return _probe(dev, tries, False)
+
+
+def _probe(dev, tries: int, with_collectives: bool) -> "torch.cuda.Stream":
     import torch.distributed as dist
-    dp = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    dp = with_collectives and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
     main = torch.cuda.current_stream(dev)
     with torch.cuda.device(dev):
         buf = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=dev).zero_()

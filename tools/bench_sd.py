@@ -78,6 +78,30 @@ def cpu_baseline(batch=1, steps=1):
             "host_cpu_count": os.cpu_count(), "torch_version": torch.__version__}
 
 
+def _aten_origins(step):
+    """Which library kernels still run inside a step, and who asks for them (the own kernels are launched through ctypes
+    and do not appear as operators)."""
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        step()
+        torch.cuda.synchronize()
+    rows = {}
+    for e in prof.events():
+        dt = getattr(e, "self_device_time_total", 0) or 0
+        if dt <= 0 or e.device_type != torch.autograd.DeviceType.CPU:
+            continue
+        ours = [fr for fr in (e.stack or []) if "unlearn_saliency_amd" in fr or "tools/" in fr]
+        key = (e.name, " <- ".join(f.split("unlearn_saliency_amd/")[-1].strip() for f in ours[:3]))
+        r = rows.setdefault(key, [0, 0.0, set()])
+        r[0] += 1
+        r[1] += dt
+        r[2].add(str(getattr(e, "input_shapes", "")))
+    tot = sum(r[1] for r in rows.values())
+    print(f"[aten_origins] {sum(r[0] for r in rows.values())} operator calls with device time, {tot / 1e3:.2f} ms in one step", file=sys.stderr)
+    for (name, where), r in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
+        print(f"[aten_origins] {r[1] / 1e3:8.3f} ms {r[0]:5d}x  {name:32s} {where}", file=sys.stderr)
+
+
 def main(argv=None):
     out = run(argv)
     from unlearn_saliency_amd import dist as sdist
@@ -104,6 +128,9 @@ def run(argv=None):
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--library_conv", action="store_true")
     ap.add_argument("--own_linear", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--aten_origins", action="store_true",
+                    help="diagnostic: one extra step under torch.profiler; the library (ATen) device kernels of the step "
+                         "grouped by operator and the calling frames of this package go to stderr")
     ap.add_argument("--library_linear", action="store_true",
                     help="A/B: leave the transformer blocks' Linear layers on the library GEMM (hipBLASLt under autocast) "
                          "instead of K16 (forward / input gradient) + K11 (weight gradient)")
@@ -198,6 +225,8 @@ def run(argv=None):
     hostperf.freeze_gc()  # what the training loops of train_scripts.py do before their first step
     steps_(a.warmup)
     torch.cuda.synchronize()
+    if a.aten_origins:
+        _aten_origins(lambda: steps_(1))
     sdist.barrier()
     if os.environ.get("SALUN_SYNC_DEBUG"):  # diagnostics: warn on every host-synchronising call inside the timed steps
         torch.cuda.set_sync_debug_mode(1)

@@ -343,6 +343,18 @@ int salun_conv3x3_packed(const float *x /*dev*/, const float *img /*dev*/, const
 int salun_conv2d_bf16_supported(int C, int K, int R, int stride, int pad);
 int salun_conv2d_bf16_pack_weights(const float *w /*dev, OIHW*/, uint16_t *wp /*dev*/, int K, int C, int R,
                                    salun_stream_t stream);
+/* Every stale weight image of a model in one launch per SALUN_BF16_PACK_MAX_JOBS layers (after an optimizer step all of
+ * them are stale; the reference has no counterpart — autocast re-casts each weight on every use,
+ * SD/train-scripts/nsfw_removal.py:96-150 under torch.autocast).  `transposed` (R == 1 only): the [C][K] image the Linear
+ * layers' input-gradient GEMM reads (what salun_pack_bf16(..., transposed = 1) writes); otherwise wp[K][R*R][C] as above.
+ * `jobs` is host memory, read during the call. */
+#define SALUN_BF16_PACK_MAX_JOBS 64
+typedef struct {
+  const float *w;  /* dev, fp32 OIHW [K][C][R][R] */
+  uint16_t *wp;    /* dev, bf16 image */
+  int32_t K, C, R, transposed;
+} salun_bf16_pack_job_t;
+int salun_bf16_pack_weights_batch(const salun_bf16_pack_job_t *jobs, int n, salun_stream_t stream);
 /* `ws` of forward / backward_data (salun_conv2d_bf16_data_workspace_bytes, may be 0): problems with few output tiles
  * split their reduction over workgroups through fp32 partial tiles there; NULL / too small only disables the split. */
 size_t salun_conv2d_bf16_data_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad);
@@ -359,6 +371,14 @@ int salun_conv2d_bf16_backward_weight(const uint16_t *x /*dev*/, const uint16_t 
                                       float *db /*dev or NULL*/, int N, int H, int W, int C, int K, int R, int stride,
                                       int pad, int accumulate, void *ws /*dev*/, size_t ws_bytes,
                                       salun_stream_t stream);
+/* The same with `dnb` (dev fp32 [N][K] or NULL, N <= 128, always overwritten): the per-image channel sums of dy — the
+ * gradient of the forward's `nbias[n][k]` term (a ResBlock's time-embedding projection,
+ * SD/ldm/modules/diffusionmodules/openaimodel.py:249-263: `h = h + emb_out[..., None, None]`), from the partial sums the
+ * bias gradient is folded from anyway (no fp32 copy of dy, no separate reduction).  db may be NULL then. */
+int salun_conv2d_bf16_backward_weight_ex(const uint16_t *x /*dev*/, const uint16_t *dy /*dev*/, float *dw /*dev*/,
+                                         float *db /*dev or NULL*/, float *dnb /*dev or NULL*/, int N, int H, int W, int C,
+                                         int K, int R, int stride, int pad, int accumulate, void *ws /*dev*/,
+                                         size_t ws_bytes, salun_stream_t stream);
 
 /* ------------------------------------------------------------------ K12 --
  * GroupNorm (+ SiLU) on bf16 NHWC activations with fp32 statistics — the `GroupNorm32` layers of the SD U-Net in its

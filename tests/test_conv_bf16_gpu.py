@@ -156,3 +156,102 @@ def test_linear_on_the_1x1_kernels_matches_fp32_linear(M_shape, C, K, bias):
     print(M_shape, C, K, {k: f"{v:.1e}" for k, v in errs.items()})
     assert errs["y"] <= 2e-2 and errs["dx"] <= 2e-2 and errs["dw"] <= 1e-2 and errs["dres"] == 0.0
     assert not bias or errs["db"] <= 1e-2
+
+
+def test_batched_weight_images_equal_the_single_launch_images_bit_for_bit():
+    """salun_bf16_pack_weights_batch (one launch per 64 layers, round 6) writes what salun_conv2d_bf16_pack_weights /
+    salun_pack_bf16(transposed) write — 3x3, 1x1, Linear, transposed Linear, channel counts that are not multiples of 32
+    in the transposed tiles, more jobs than one launch takes."""
+    from unlearn_saliency_amd import ops
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 32, 3), (320, 640, 3), (96, 64, 1), (1280, 320, 1), (32, 32, 3)] + [(32 + 8 * (i % 5), 40 + 8 * (i % 3), 1) for i in range(70)]
+    jobs, want = [], []
+    for K, C, R in shapes:
+        w = torch.randn(K, C, R, R, generator=g).cuda()
+        img = torch.empty((K, R * R, C), dtype=torch.bfloat16, device="cuda")
+        jobs.append((w, img, K, C, R, False))
+        want.append(ops.conv2d_bf16_pack(w))
+        if R == 1:
+            imt = torch.empty((C, K), dtype=torch.bfloat16, device="cuda")
+            jobs.append((w.view(K, C), imt, K, C, 1, True))
+            want.append(ops.pack_bf16(w.view(K, C), True))
+    n = ops.bf16_pack_batch(jobs)
+    assert n == (len(jobs) + 63) // 64 and n >= 2
+    for (w, img, *_), ref in zip(jobs, want):
+        assert torch.equal(img.view(torch.int16), ref.view(torch.int16).view(img.shape))
+
+
+def test_a_model_packs_all_its_layers_in_one_batch_per_step():
+    from unlearn_saliency_amd import conv_bf16, ops
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(32, 64, 3, padding=1), torch.nn.Conv2d(64, 64, 1), torch.nn.Conv2d(64, 32, 3, padding=1)).cuda()
+    assert conv_bf16.use_salun_convs_bf16(net) == 3
+    x = torch.randn(2, 32, 16, 16, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref = lambda: torch.nn.Sequential(*[torch.nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, padding=m.padding) for m in net])
+    n0 = conv_bf16.PACK_LAUNCHES[0]
+    y = net(x)
+    assert conv_bf16.PACK_LAUNCHES[0] == n0 + 1
+    conv_bf16.BATCH_PACKS[0] = False
+    try:
+        ops.PARAM_EPOCH[0] += 1
+        y1 = net(x)                      # one launch per layer: the same images
+        assert conv_bf16.PACK_LAUNCHES[0] == n0 + 4 and torch.equal(y, y1)
+    finally:
+        conv_bf16.BATCH_PACKS[0] = True
+    with torch.no_grad():
+        net[1].weight.mul_(0.5)
+    y2 = net(x)
+    assert conv_bf16.PACK_LAUNCHES[0] == n0 + 5 and not torch.equal(y, y2)
+
+
+# (N, H, W, C, K, R): the tap kernels (3x3), the dY^T.X GEMM route (1x1 with >= 1024 pixels), images smaller than one chunk,
+# a batch that does not divide the 128 chunk slots, the 1x1 tap route (few pixels)
+@pytest.mark.parametrize("dims", [(8, 16, 16, 64, 96, 3), (8, 32, 32, 64, 128, 1), (3, 5, 7, 32, 160, 3), (48, 8, 8, 32, 64, 3),
+                                  (2, 8, 8, 64, 64, 1), (128, 4, 4, 32, 32, 3)])
+def test_per_image_channel_sums_ride_on_the_bias_gradient(dims):
+    """salun_conv2d_bf16_backward_weight_ex: dnb[n][k] = sum over the pixels of image n of dy (the gradient of the forward's
+    nbias term) from the bias gradient's partial sums; db and dw are what the call without dnb gives (db: another
+    summation order, fp32 rounding)."""
+    from unlearn_saliency_amd import ops
+    N, H, W, C, K, R = dims
+    x, dy = _mk((N, H, W, C), 11), _mk((N, H, W, K), 12)
+    pad = R // 2
+    db0 = torch.zeros(K, device="cuda")
+    dw0 = ops.conv2d_bf16_backward_weight(x, dy, (K, C, R, R), 1, pad, bias_out=db0)
+    db1 = torch.zeros(K, device="cuda")
+    dnb = torch.full((N, K), float("nan"), device="cuda")
+    dw1 = ops.conv2d_bf16_backward_weight(x, dy, (K, C, R, R), 1, pad, bias_out=db1, nbias_out=dnb)
+    assert torch.equal(dw0, dw1)
+    ref = dy.double().sum(dim=(1, 2))
+    scale = float(ref.abs().max())
+    assert float((dnb.double() - ref).abs().max()) <= 1e-5 * scale
+    assert float((db1.double() - ref.sum(0)).abs().max()) <= 1e-5 * float(ref.sum(0).abs().max() + scale)
+    assert float((db0 - db1).abs().max()) <= 1e-5 * float(db0.abs().max())
+    # without a bias gradient, and accumulating db: dnb is overwritten all the same
+    dnb2 = torch.full((N, K), 7.0, device="cuda")
+    acc = torch.ones(K, device="cuda")
+    out = torch.zeros(K, C, R, R, device="cuda")
+    ops.conv2d_bf16_backward_weight(x, dy, (K, C, R, R), 1, pad, out=out, accumulate=True, bias_out=acc, nbias_out=dnb2)
+    assert torch.equal(dnb2, dnb) and float((acc - 1 - db1).abs().max()) <= 1e-5 * float(db1.abs().max())
+    dnb3 = torch.empty((N, K), device="cuda")
+    ops.conv2d_bf16_backward_weight(x, dy, (K, C, R, R), 1, pad, nbias_out=dnb3)
+    assert torch.equal(dnb3, dnb)
+
+
+def test_resblock_time_embedding_gradient_through_the_fused_sums():
+    """SalunConv2dBF16(x, nbias=emb): emb.grad from the kernel equals dy.float().sum over the pixels (what autograd computed
+    from a copy of dy before round 6), weights trainable or frozen."""
+    from unlearn_saliency_amd import conv_bf16
+    torch.manual_seed(3)
+    for frozen in (False, True):
+        conv = torch.nn.Conv2d(64, 96, 3, padding=1).cuda()
+        conv.__class__ = conv_bf16.SalunConv2dBF16
+        conv.weight.requires_grad_(not frozen)
+        conv.bias.requires_grad_(not frozen)
+        x = torch.randn(4, 64, 16, 16, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        emb = torch.randn(4, 96, device="cuda", requires_grad=True)
+        y = conv(x, nbias=emb)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        ref = dy.float().sum(dim=(2, 3))
+        assert float((emb.grad - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

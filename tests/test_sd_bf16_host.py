@@ -160,3 +160,41 @@ def test_forget_and_target_on_host_tensors_is_the_plain_sequence():
     assert [g for _, g in calls] == [True, False] and calls[0][0] is c_f and calls[1][0] is c_t
     assert out.requires_grad and not tgt.requires_grad
     assert torch.equal(out.detach(), z.detach() * 2.0 + 1.0) and torch.equal(tgt, z.detach() * 2.0)
+
+
+def test_registered_modules_repack_together_once_per_parameter_epoch():
+    """Round 6: after an optimizer step every weight image of a model is stale; the first one asked for re-packs ALL of
+    them in one batch (conv_bf16._repack_stale -> ops.bf16_pack_batch), later requests are cache hits; a second model's
+    modules on another device are not touched; a torch write on one weight re-packs that weight alone."""
+    from unlearn_saliency_amd import conv_bf16, ops
+    from unlearn_saliency_amd.SD.unet import UNetModel
+    m = UNetModel(**sd_tiny_config())
+    n_conv = conv_bf16.use_salun_convs_bf16(m)
+    n_lin = conv_bf16.use_salun_linears_bf16(m)
+    mods = [x for x in m.modules() if isinstance(x, (conv_bf16.SalunConv2dBF16, conv_bf16.SalunLinearBF16))]
+    assert len(mods) == n_conv + n_lin and all(getattr(x, "_salun_pack_registered", False) for x in mods)
+    batches = []
+    real = ops.bf16_pack_batch
+    ops.bf16_pack_batch = lambda jobs: batches.append(list(jobs)) or 1
+    try:
+        first = mods[0].packed_weight()
+        assert len(batches) == 1
+        mine = [j for j in batches[0] if any(j[0].data_ptr() == x.weight.data_ptr() for x in mods)]
+        assert len(mine) == n_conv + 2 * n_lin          # every Linear: the [K, C] image and the transposed one
+        assert all(j[5] in (False, True) and j[1].dtype == torch.bfloat16 for j in mine)
+        for x in mods:                                   # all fresh now: no further batch
+            x.packed_weight()
+            if isinstance(x, conv_bf16.SalunLinearBF16):
+                assert tuple(x.packed_weight_t().shape) == (x.in_features, x.out_features)
+        assert len(batches) == 1 and mods[0].packed_weight() is first
+        ops.PARAM_EPOCH[0] += 1                          # an optimizer step through raw pointers
+        mods[3].packed_weight()
+        assert len(batches) == 2 and len([j for j in batches[1] if any(j[0].data_ptr() == x.weight.data_ptr() for x in mods)]) == len(mine)
+        assert mods[0].packed_weight() is first          # buffers are reused
+        with torch.no_grad():
+            mods[1].weight.mul_(2.0)                     # torch's own version counter: this weight alone
+        mods[1].packed_weight()
+        assert len(batches) == 3
+        assert [j[0].data_ptr() for j in batches[2]].count(mods[1].weight.data_ptr()) == len(batches[2])
+    finally:
+        ops.bf16_pack_batch = real

@@ -46,6 +46,13 @@ class PackJob(ctypes.Structure):
                 ("C", ctypes.c_int32)]
 
 
+class Bf16PackJob(ctypes.Structure):
+    """salun_bf16_pack_job_t"""
+    _fields_ = [("w", c_void_p), ("wp", c_void_p), ("K", ctypes.c_int32), ("C", ctypes.c_int32), ("R", ctypes.c_int32),
+                ("transposed", ctypes.c_int32)]
+
+
+SALUN_BF16_PACK_MAX_JOBS = 64
 SALUN_GEMM_MAX_JOBS = 32
 SALUN_GEMM_MAX_SEGS = 32
 
@@ -101,11 +108,13 @@ SIGNATURES = {
                                                                                                  c_size_t, c_void_p]),
     "salun_conv2d_bf16_supported": (c_int, [c_int] * 5),
     "salun_conv2d_bf16_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "salun_bf16_pack_weights_batch": (c_int, [c_void_p, c_int, c_void_p]),
     "salun_conv2d_bf16_data_workspace_bytes": (c_size_t, [c_int] * 8),
     "salun_conv2d_bf16_forward": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_bf16_backward_data": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_bf16_wgrad_workspace_bytes": (c_size_t, [c_int] * 8),
     "salun_conv2d_bf16_backward_weight": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
+    "salun_conv2d_bf16_backward_weight_ex": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
     "salun_gn_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
     "salun_gn_bf16_forward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_double, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_gn_bf16_backward": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),

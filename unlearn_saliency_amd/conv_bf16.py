@@ -59,18 +59,83 @@ class _ConvBF16Fn(FastFunction):
             if ctx.has_bias and bdst is None:
                 bdst = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
                 db = bdst
-            got = ops.conv2d_bf16_backward_weight(xn, dyn, tuple(w.shape), s, p, out=dst, accumulate=True, bias_out=bdst)
+            if ctx.nbias and ctx.needs_input_grad[4] and dyn.shape[0] <= 128:
+                # per-image channel sums of dy out of the bias gradient's partial sums (one kernel pair for both)
+                dnb = torch.empty((dyn.shape[0], w.shape[0]), dtype=torch.float32, device=dyn.device)
+            got = ops.conv2d_bf16_backward_weight(xn, dyn, tuple(w.shape), s, p, out=dst, accumulate=True, bias_out=bdst,
+                                                  nbias_out=dnb)
             if dst is None:
                 dw = got
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_bf16_backward_data(dyn, mod.packed_weight(), tuple(xn.shape), R, s, p).permute(0, 3, 1, 2)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
-        if ctx.nbias and ctx.needs_input_grad[4]:
+        if ctx.nbias and ctx.needs_input_grad[4] and dnb is None:  # (frozen weights: no backward-weight launch to ride on)
             dnb = dyn.float().sum(dim=(1, 2))
         if ctx.addend_dtype is not None and ctx.needs_input_grad[5]:
             dadd = dy if dy.dtype == ctx.addend_dtype else dy.to(ctx.addend_dtype)
         return dx, dw, db, None, dnb, dadd
+
+
+# ------------------------------------------------------------------------------------------- weight images
+# After an optimizer step EVERY bf16 weight image of a model is stale.  One pack launch per layer at its first use was
+# 256 launches of ~13 us per SD step (round 5 profile: 1.4 % of the device time, most launches far too small to fill the
+# chip); the modules `use_salun_convs_bf16` / `use_salun_linears_bf16` re-classed are therefore REGISTERED, and the first
+# stale image any of them asks for re-packs all stale images of that device in ceil(n / 64) launches (csrc:
+# k_pack_jobs).  A module that was never registered (built by hand in a test) packs alone, as before.
+import weakref as _weakref
+
+_REGISTERED: list = []      # weak references, in registration order (the order of use in a forward pass)
+_IS_REGISTERED = "_salun_pack_registered"
+import os as _os0
+BATCH_PACKS = [_os0.environ.get("SALUN_BF16_BATCH_PACK", "1") != "0"]  # A/B switch: False = one launch per image at its first use
+PACK_LAUNCHES = [0]
+
+
+def _register(mod) -> None:
+    if not getattr(mod, _IS_REGISTERED, False):
+        setattr(mod, _IS_REGISTERED, True)
+        _REGISTERED.append(_weakref.ref(mod))
+
+
+def _weight_key(w):
+    # PARAM_EPOCH: bumped by every kernel that rewrites parameters through raw pointers; w._version: torch writes
+    # on the parameter itself; the flat arena's version: torch writes on `arena.params` (or any slice of it) do
+    # NOT bump the parameter's own counter — `p.data = view` gave it a separate one (flat.py)
+    flat = getattr(w, "_salun_flat", None)
+    return (ops.PARAM_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
+
+
+def _repack_stale(device) -> None:
+    """Every registered module on `device` whose image(s) do not match its weight: one batch on the current stream."""
+    jobs, done, alive = [], [], []
+    for ref in _REGISTERED:
+        mod = ref()
+        if mod is None:
+            continue
+        alive.append(ref)
+        w = mod.weight
+        if w.device != device:
+            continue
+        key = _weight_key(w)
+        lin = isinstance(mod, SalunLinearBF16)
+        K, C = w.shape[0], w.shape[1]
+        R = 1 if lin else mod.kernel_size[0]
+        if mod._pack is None or mod._pack_key != key or mod._pack.device != device:
+            if mod._pack is None or mod._pack.device != device:
+                mod._pack = torch.empty((K, R * R, C), dtype=torch.bfloat16, device=device)
+            jobs.append((w.detach(), mod._pack, K, C, R, False))
+            done.append((mod, "_pack_key", key))
+        if lin and (mod._pack_t is None or mod._pack_t_key != key or mod._pack_t.device != device):
+            if mod._pack_t is None or mod._pack_t.device != device:
+                mod._pack_t = torch.empty((C, K), dtype=torch.bfloat16, device=device)
+            jobs.append((w.detach(), mod._pack_t, K, C, 1, True))
+            done.append((mod, "_pack_t_key", key))
+    if len(alive) != len(_REGISTERED):
+        _REGISTERED[:] = alive
+    PACK_LAUNCHES[0] += ops.bf16_pack_batch(jobs)
+    for mod, attr, key in done:
+        setattr(mod, attr, key)
 
 
 class SalunConv2dBF16(nn.Conv2d):
@@ -81,14 +146,14 @@ class SalunConv2dBF16(nn.Conv2d):
 
     def packed_weight(self) -> torch.Tensor:
         w = self.weight
-        # PARAM_EPOCH: bumped by every kernel that rewrites parameters through raw pointers; w._version: torch writes
-        # on the parameter itself; the flat arena's version: torch writes on `arena.params` (or any slice of it) do
-        # NOT bump the parameter's own counter — `p.data = view` gave it a separate one (flat.py)
-        flat = getattr(w, "_salun_flat", None)
-        key = (ops.PARAM_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
+        key = _weight_key(w)
         if self._pack is None or self._pack_key != key or self._pack.device != w.device:
-            self._pack = ops.conv2d_bf16_pack(w.detach(), self._pack if self._pack is not None and self._pack.device == w.device else None)
-            self._pack_key = key
+            if BATCH_PACKS[0] and getattr(self, _IS_REGISTERED, False):
+                _repack_stale(w.device)
+            else:
+                self._pack = ops.conv2d_bf16_pack(w.detach(), self._pack if self._pack is not None and self._pack.device == w.device else None)
+                self._pack_key = key
+                PACK_LAUNCHES[0] += 1
         return self._pack
 
     def forward(self, x, nbias=None, addend=None):
@@ -193,19 +258,21 @@ class SalunLinearBF16(nn.Linear):
     _pack_t_key = None
 
     def _key(self):
-        w = self.weight
-        flat = getattr(w, "_salun_flat", None)
-        return (ops.PARAM_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
+        return _weight_key(self.weight)
 
     def packed_weight(self) -> torch.Tensor:
         """bf16 image [N, 1, K] (= [N, K]) of the master weights, re-packed once per optimizer step."""
         w = self.weight
         key = self._key()
         if self._pack is None or self._pack_key != key or self._pack.device != w.device:
-            K, C = w.shape
-            self._pack = ops.conv2d_bf16_pack(w.detach().view(K, C, 1, 1),
-                                              self._pack if self._pack is not None and self._pack.device == w.device else None)
-            self._pack_key = key
+            if BATCH_PACKS[0] and getattr(self, _IS_REGISTERED, False):
+                _repack_stale(w.device)
+            else:
+                K, C = w.shape
+                self._pack = ops.conv2d_bf16_pack(w.detach().view(K, C, 1, 1),
+                                                  self._pack if self._pack is not None and self._pack.device == w.device else None)
+                self._pack_key = key
+                PACK_LAUNCHES[0] += 1
         return self._pack
 
     def packed_weight_t(self) -> torch.Tensor:
@@ -213,9 +280,13 @@ class SalunLinearBF16(nn.Linear):
         w = self.weight
         key = self._key()
         if self._pack_t is None or self._pack_t_key != key or self._pack_t.device != w.device:
-            self._pack_t = ops.pack_bf16(w.detach(), True,
-                                         self._pack_t if self._pack_t is not None and self._pack_t.device == w.device else None)
-            self._pack_t_key = key
+            if BATCH_PACKS[0] and getattr(self, _IS_REGISTERED, False):
+                _repack_stale(w.device)
+            else:
+                self._pack_t = ops.pack_bf16(w.detach(), True,
+                                             self._pack_t if self._pack_t is not None and self._pack_t.device == w.device else None)
+                self._pack_t_key = key
+                PACK_LAUNCHES[0] += 1
         return self._pack_t
 
     def forward(self, x, addend=None):
@@ -240,6 +311,7 @@ def use_salun_linears_bf16(model: nn.Module) -> int:
             if type(mod) is nn.Linear and mod.in_features % 32 == 0 and mod.out_features % 32 == 0 and \
                     ops.conv2d_bf16_supported(mod.in_features, mod.out_features, 1, 1, 0):
                 mod.__class__ = SalunLinearBF16
+                _register(mod)
                 n += 1
     return n
 
@@ -266,6 +338,7 @@ def use_salun_convs_bf16(model: nn.Module) -> int:
         R, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
         if C % 32 == 0 and K % 32 == 0 and ops.conv2d_bf16_supported(C, K, R, s, p):
             mod.__class__ = SalunConv2dBF16
+            _register(mod)
             n += 1
         else:
             mod.__class__ = _Fp32Island

@@ -81,6 +81,82 @@ __global__ __launch_bounds__(256) void k_pack_w(const float *__restrict__ w, uin
   }
 }
 
+// The same for a whole model in a few launches (round 6): after an optimizer step every weight image is stale, and one
+// launch per layer was 256 launches of ~13 us per SD step, most of them too small to fill the chip.  blockIdx.y = job;
+// `transposed` jobs (R = 1) write the [C][K] image the Linear layers' input-gradient GEMM reads (k_pack_bf16_t's tiles).
+struct PackJobsB {
+  struct J { const float *w; uint16_t *wp; int K, C, RS, transposed; } j[SALUN_BF16_PACK_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void k_pack_jobs(const PackJobsB jobs) {
+  __shared__ float tile[32][33];
+  const float *__restrict__ w = jobs.j[blockIdx.y].w;
+  uint16_t *__restrict__ wp = jobs.j[blockIdx.y].wp;
+  const int K = jobs.j[blockIdx.y].K, C = jobs.j[blockIdx.y].C, RS = jobs.j[blockIdx.y].RS;
+  if (!jobs.j[blockIdx.y].transposed) {
+    // one thread = 8 channels of one filter, all taps: 8 * RS CONSECUTIVE floats of the OIHW weights (k_pack_w reads
+    // them as 8 * RS separate dwords at a stride of RS: a third of the streaming rate on the 3x3 layers), written as RS
+    // 16-byte pieces of the image, each coalesced over the threads of a wave
+    const int c8n = C >> 3;
+    const int64_t total = (int64_t)K * c8n;
+    const bool al16 = (reinterpret_cast<uintptr_t>(w) & 15) == 0;  // (a view at any 4-byte offset of the flat arena)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int c8 = (int)(i % c8n);
+      const int64_t k = i / c8n;
+      const float *src = w + (k * C + (int64_t)c8 * 8) * RS;
+      uint16_t *dst = wp + (k * RS) * C + (int64_t)c8 * 8;
+      if (RS == 9) {
+        float v[72];
+        if (al16) {
+#pragma unroll
+          for (int q = 0; q < 18; ++q) {
+            const float4 t = reinterpret_cast<const float4 *>(src)[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 72; ++q) v[q] = src[q];
+        }
+#pragma unroll
+        for (int rs = 0; rs < 9; ++rs) {
+          uint32_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = pack2(v[(2 * q) * 9 + rs], v[(2 * q + 1) * 9 + rs]);
+          *reinterpret_cast<uint4 *>(dst + (int64_t)rs * C) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      } else {  // RS == 1
+        float v[8];
+        if (al16) {
+          const float4 a = reinterpret_cast<const float4 *>(src)[0], b = reinterpret_cast<const float4 *>(src)[1];
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = src[q];
+        }
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+      }
+    }
+    return;
+  }
+  // w [K][C] fp32 -> wp [C][K] bf16, 32 x 32 tiles through LDS
+  const int tc = (C + 31) / 32, tk = (K + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int t = blockIdx.x; t < tc * tk; t += gridDim.x) {
+    const int c0 = (t % tc) * 32, k0 = (t / tc) * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + ty + 8 * r, c = c0 + tx;
+      tile[ty + 8 * r][tx] = (k < K && c < C) ? w[(size_t)k * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + ty + 8 * r, k = k0 + tx;
+      if (c < C && k < K) wp[(size_t)c * K + k] = f2bf(tile[tx][ty + 8 * r]);
+    }
+    __syncthreads();
+  }
+}
+
 // --------------------------------------------------------------------------------------- forward / backward-data
 struct IgArgs {
   const uint16_t *x;       // [N][H][W][Cin] bf16 (forward: input; backward-data: dY)
@@ -683,13 +759,19 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_bf16(const float *__restri
 // per-channel sum over pixels of an NHWC bf16 tensor (the bias gradient): [M][K] -> fp32 [K], two deterministic stages.
 // Stage 1: block = 32 channel groups (8 channels each, one 16-byte load) x 8 row lanes over one row chunk.
 constexpr int COLSUM_CHUNKS = 128;
+// With `cpi` chunks per image (rows_per_image = OH * OW) no chunk straddles two images, and the finish kernel can also give
+// the per-image sums dnb[n][k] — the gradient of the per-image channel offset `nbias` of the forward epilogue (a ResBlock's
+// time-embedding term), which was a bf16 -> fp32 copy of dy plus a library reduction per ResBlock convolution before round 6.
+// Without dnb the launcher passes rows_per_image = M, cpi = chunks: the walk of rounds 2 - 5.
 __global__ __launch_bounds__(256) void k_colsum_partial(const uint16_t *__restrict__ dy, float *__restrict__ part, int64_t M,
-                                                        int K, int64_t rows_per_chunk) {
+                                                        int K, int64_t rows_per_chunk, int64_t rows_per_image, int cpi) {
   __shared__ float s[8][32][9];
   const int gx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int k = (blockIdx.x * 32 + gx) * 8;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
-  const int64_t r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
+  const int img = blockIdx.y / cpi;
+  const int64_t i1 = (int64_t)(img + 1) * rows_per_image < M ? (int64_t)(img + 1) * rows_per_image : M;
+  const int64_t r0 = (int64_t)img * rows_per_image + (int64_t)(blockIdx.y - img * cpi) * rows_per_chunk;
+  const int64_t r1 = r0 + rows_per_chunk < i1 ? r0 + rows_per_chunk : i1;
   float a[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) a[j] = 0.f;
@@ -711,20 +793,58 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const uint16_t *__restri
     }
   }
 }
+// out[k] (=, += or not at all) and, with dnb, dnb[n][k] = the sum of image n's chunks (chunks = images * cpi then)
 __global__ __launch_bounds__(256) void k_colsum_finish(const float *__restrict__ part, float *__restrict__ out, int K, int chunks,
-                                                       int accumulate) {
+                                                       int accumulate, float *__restrict__ dnb, int cpi) {
   __shared__ float s[8][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int k = blockIdx.x * 32 + cx;
   float t = 0.f;
-  if (k < K)
-    for (int c = ry; c < chunks; c += 8) t += part[(size_t)c * K + k];
+  if (k < K) {
+    if (dnb) {
+      for (int n = ry; n * cpi < chunks; n += 8) {
+        float u = 0.f;
+        for (int c = 0; c < cpi; ++c) u += part[(size_t)(n * cpi + c) * K + k];
+        dnb[(size_t)n * K + k] = u;
+        t += u;
+      }
+    } else {
+      for (int c = ry; c < chunks; c += 8) t += part[(size_t)c * K + k];
+    }
+  }
   s[ry][cx] = t;
   __syncthreads();
-  if (ry == 0 && k < K) {
+  if (ry == 0 && k < K && out) {
     t = ((s[0][cx] + s[1][cx]) + (s[2][cx] + s[3][cx])) + ((s[4][cx] + s[5][cx]) + (s[6][cx] + s[7][cx]));
     out[k] = accumulate ? out[k] + t : t;
   }
+}
+
+// the two launches of a bias gradient (and, with dnb, of the per-image sums); `cpart`: COLSUM_CHUNKS * K floats
+int launch_colsum(const uint16_t *dy, float *cpart, float *db, float *dnb, int64_t M, int K, int images, int accumulate,
+                  hipStream_t st) {
+  int chunks, cpi;
+  int64_t rpc, rpi;
+  if (dnb) {
+    if (images < 1 || images > COLSUM_CHUNKS || M % images) return SALUN_EINVAL;
+    rpi = M / images;
+    cpi = COLSUM_CHUNKS / images;
+    if ((int64_t)cpi > (rpi + 63) / 64) cpi = (int)((rpi + 63) / 64);
+    if (cpi < 1) cpi = 1;
+    rpc = (rpi + cpi - 1) / cpi;
+    chunks = images * cpi;
+  } else {
+    chunks = (int)((M + 63) / 64);
+    if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
+    rpc = (M + chunks - 1) / chunks;
+    rpi = M;
+    cpi = chunks;
+  }
+  hipLaunchKernelGGL(k_colsum_partial, dim3((K / 8 + 31) / 32, chunks), dim3(256), 0, st, dy, cpart, M, K, rpc, rpi, cpi);
+  SALUN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, cpart, db, K, chunks, accumulate, dnb, cpi);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
 }
 
 #ifndef SALUN_BF16_WGRAD_TARGET
@@ -858,6 +978,26 @@ SALUN_EXPORT int salun_conv2d_bf16_pack_weights(const float *w, uint16_t *wp, in
   return SALUN_OK;
 }
 
+SALUN_EXPORT int salun_bf16_pack_weights_batch(const salun_bf16_pack_job_t *jobs, int n, salun_stream_t stream) {
+  if (!jobs || n < 1 || n > SALUN_BF16_PACK_MAX_JOBS) return SALUN_EINVAL;
+  PackJobsB pj;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const salun_bf16_pack_job_t &q = jobs[i];
+    if (!q.w || !q.wp || q.K < 1 || q.C < 8 || (q.R != 1 && q.R != 3) || (q.transposed && q.R != 1)) return SALUN_EINVAL;
+    if (!q.transposed && (q.C % 8 || !salun_aligned16(q.wp))) return SALUN_EINVAL;
+    pj.j[i] = {q.w, q.wp, q.K, q.C, q.R * q.R, q.transposed ? 1 : 0};
+    const int64_t blocks = q.transposed ? (int64_t)((q.C + 31) / 32) * ((q.K + 31) / 32)
+                                        : ((int64_t)q.K * (q.C / 8) + 255) / 256;
+    if (blocks > most) most = blocks;
+  }
+  // grid.x: enough workgroups for the largest job to spread over the chip; the jobs loop over what is left
+  const unsigned gx = (unsigned)(most < 1 ? 1 : (most > 256 ? 256 : most));
+  hipLaunchKernelGGL(k_pack_jobs, dim3(gx, (unsigned)n), dim3(256), 0, salun_hip_stream(stream), pj);
+  SALUN_LAUNCH_CHECK();
+  return SALUN_OK;
+}
+
 // Scratch for the reduction split of forward / backward-data: 16 fp32 copies of the larger of the two outputs is the
 // most any plan uses; a smaller (or null) workspace only disables the split.
 SALUN_EXPORT size_t salun_conv2d_bf16_data_workspace_bytes(int N, int H, int W, int C, int K, int R, int stride, int pad) {
@@ -954,12 +1094,14 @@ SALUN_EXPORT size_t salun_conv2d_bf16_wgrad_workspace_bytes(int N, int H, int W,
   return tap;
 }
 
-// dw fp32 OIHW [K][C][R][R] (+= when accumulate); db fp32 [K] or null (the bias gradient, += when accumulate)
-SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N,
-                                                   int H, int W, int C, int K, int R, int stride, int pad, int accumulate,
-                                                   void *ws, size_t ws_bytes, salun_stream_t stream) {
+// dw fp32 OIHW [K][C][R][R] (+= when accumulate); db fp32 [K] or null (the bias gradient, += when accumulate); dnb fp32
+// [N][K] or null (per-image channel sums of dy: the gradient of the forward's `nbias`, always overwritten)
+SALUN_EXPORT int salun_conv2d_bf16_backward_weight_ex(const uint16_t *x, const uint16_t *dy, float *dw, float *db, float *dnb,
+                                                      int N, int H, int W, int C, int K, int R, int stride, int pad,
+                                                      int accumulate, void *ws, size_t ws_bytes, salun_stream_t stream) {
   if (!x || !dy || !dw || !ws || N < 1 || !supported(C, K, R, stride, pad)) return SALUN_EINVAL;
   if (!salun_aligned16(x) || !salun_aligned16(dy)) return SALUN_EINVAL;
+  if (dnb && N > COLSUM_CHUNKS) return SALUN_EINVAL;
   const size_t need = salun_conv2d_bf16_wgrad_workspace_bytes(N, H, W, C, K, R, stride, pad);
   if (ws_bytes < need) return SALUN_ENOSPC;
   const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - R) / stride + 1;
@@ -968,17 +1110,10 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
     size_t gb = salun_gemm_bf16_tn_workspace_bytes(M, K, C, 0);
     const int rc = salun_gemm_bf16_tn(dy, x, dw, M, K, C, accumulate, 0, ws, gb, stream);
     if (rc != SALUN_OK) return rc;
-    if (db) {
+    if (db || dnb) {
       gb = (gb + 255) & ~(size_t)255;
-      hipStream_t st = salun_hip_stream(stream);
-      int chunks = (int)((M + 63) / 64);
-      if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
-      const int64_t rpc = (M + chunks - 1) / chunks;
       float *cpart = reinterpret_cast<float *>(static_cast<char *>(ws) + gb);
-      hipLaunchKernelGGL(k_colsum_partial, dim3((K / 8 + 31) / 32, chunks), dim3(256), 0, st, dy, cpart, M, K, rpc);
-      SALUN_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, cpart, db, K, chunks, accumulate);
-      SALUN_LAUNCH_CHECK();
+      return launch_colsum(dy, cpart, db, dnb, M, K, N, accumulate, salun_hip_stream(stream));
     }
     return SALUN_OK;
   }
@@ -1004,16 +1139,16 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint
                        splits, accumulate);
     SALUN_LAUNCH_CHECK();
   }
-  if (db) {
-    const int64_t M = (int64_t)N * OH * OW;
-    int chunks = (int)((M + 63) / 64);
-    if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
-    const int64_t rpc = (M + chunks - 1) / chunks;
+  if (db || dnb) {
     float *cpart = a.part + (size_t)splits * R * R * K * C;
-    hipLaunchKernelGGL(k_colsum_partial, dim3((K / 8 + 31) / 32, chunks), dim3(256), 0, st, dy, cpart, M, K, rpc);
-    SALUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, cpart, db, K, chunks, accumulate);
-    SALUN_LAUNCH_CHECK();
+    return launch_colsum(dy, cpart, db, dnb, (int64_t)N * OH * OW, K, N, accumulate, st);
   }
   return SALUN_OK;
+}
+
+SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N,
+                                                   int H, int W, int C, int K, int R, int stride, int pad, int accumulate,
+                                                   void *ws, size_t ws_bytes, salun_stream_t stream) {
+  return salun_conv2d_bf16_backward_weight_ex(x, dy, dw, db, nullptr, N, H, W, C, K, R, stride, pad, accumulate, ws, ws_bytes,
+                                              stream);
 }

@@ -510,6 +510,28 @@ def conv2d_bf16_pack(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> tor
     return out
 
 
+def bf16_pack_batch(jobs) -> int:
+    """jobs: iterable of (w fp32 OIHW / [K, C], wp bf16 image, K, C, R, transposed) -> every image written by
+    ceil(n / 64) launches on the current stream (the per-model form of conv2d_bf16_pack / pack_bf16; conv_bf16.py keeps the
+    registry).  Returns the number of launches."""
+    jobs = list(jobs)
+    if not jobs:
+        return 0
+    PACK_CALLS[0] += 1
+    L, st, cap = _lib.lib(), _stream(), _lib.SALUN_BF16_PACK_MAX_JOBS
+    launches = 0
+    for i in range(0, len(jobs), cap):
+        part = jobs[i:i + cap]
+        arr = (_lib.Bf16PackJob * len(part))()
+        for a, (w, wp, K, C, R, tr) in zip(arr, part):
+            _dev(w, torch.float32, "w")
+            _dev(wp, torch.bfloat16, "wp")
+            a.w, a.wp, a.K, a.C, a.R, a.transposed = w.data_ptr(), wp.data_ptr(), K, C, R, int(bool(tr))
+        check(L.salun_bf16_pack_weights_batch(ctypes.cast(arr, c_void_p), len(part), st), "salun_bf16_pack_weights_batch")
+        launches += 1
+    return launches
+
+
 def conv2d_bf16_forward(x: torch.Tensor, wp: torch.Tensor, R: int, stride: int, pad: int,
                         bias: Optional[torch.Tensor] = None, nbias: Optional[torch.Tensor] = None,
                         addend: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -545,9 +567,11 @@ def conv2d_bf16_backward_data(dy: torch.Tensor, wp: torch.Tensor, x_shape, R: in
 
 def conv2d_bf16_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stride: int, pad: int,
                                 out: Optional[torch.Tensor] = None, accumulate: bool = False,
-                                bias_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                                bias_out: Optional[torch.Tensor] = None,
+                                nbias_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dw fp32 OIHW (written, or added into `out` when accumulate); `bias_out` (fp32 [K]) receives / accumulates the
-    per-channel sum of dy in the same call."""
+    per-channel sum of dy in the same call; `nbias_out` (fp32 [N, K], N <= 128) is overwritten with the per-image channel
+    sums of dy — the gradient of the forward's `nbias` term."""
     N, H, W, C = x.shape
     K, _, R, _ = w_shape
     L = _lib.lib()
@@ -556,11 +580,14 @@ def conv2d_bf16_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stri
         raise ValueError(f"bf16 backward-weight: unsupported shape C={C} K={K} R={R} stride={stride} pad={pad}")
     ws = workspace(nbytes, x.device)
     dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
-    check(L.salun_conv2d_bf16_backward_weight(_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"),
-                                              _dev(dw, torch.float32, "dw"), _dev(bias_out, torch.float32, "db", True),
-                                              N, H, W, C, K, R, stride, pad, int(bool(accumulate and out is not None)),
-                                              c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()),
-          "salun_conv2d_bf16_backward_weight")
+    if nbias_out is not None and tuple(nbias_out.shape) != (N, K):
+        raise ValueError(f"nbias_out must be [{N}, {K}]")
+    check(L.salun_conv2d_bf16_backward_weight_ex(_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"),
+                                                 _dev(dw, torch.float32, "dw"), _dev(bias_out, torch.float32, "db", True),
+                                                 _dev(nbias_out, torch.float32, "dnb", True),
+                                                 N, H, W, C, K, R, stride, pad, int(bool(accumulate and out is not None)),
+                                                 c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()),
+          "salun_conv2d_bf16_backward_weight_ex")
     return dw
 
 

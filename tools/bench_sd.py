@@ -82,7 +82,7 @@ def _aten_origins(step):
     """Which library kernels still run inside a step, and who asks for them (the own kernels are launched through ctypes
     and do not appear as operators)."""
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         step()
         torch.cuda.synchronize()
     rows = {}
@@ -91,14 +91,15 @@ def _aten_origins(step):
         if dt <= 0 or e.device_type != torch.autograd.DeviceType.CPU:
             continue
         ours = [fr for fr in (e.stack or []) if "unlearn_saliency_amd" in fr or "tools/" in fr]
-        key = (e.name, " <- ".join(f.split("unlearn_saliency_amd/")[-1].strip() for f in ours[:3]))
+        shapes = str(getattr(e, "input_shapes", "")) if e.name.startswith("aten::") else ""
+        key = (e.name, " <- ".join(f.split("unlearn_saliency_amd/")[-1].strip() for f in ours[:3]) + " " + shapes)
         r = rows.setdefault(key, [0, 0.0, set()])
         r[0] += 1
         r[1] += dt
         r[2].add(str(getattr(e, "input_shapes", "")))
     tot = sum(r[1] for r in rows.values())
     print(f"[aten_origins] {sum(r[0] for r in rows.values())} operator calls with device time, {tot / 1e3:.2f} ms in one step", file=sys.stderr)
-    for (name, where), r in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
+    for (name, where), r in sorted(rows.items(), key=lambda kv: -kv[1][1])[:90]:
         print(f"[aten_origins] {r[1] / 1e3:8.3f} ms {r[0]:5d}x  {name:32s} {where}", file=sys.stderr)
 
 

@@ -16,6 +16,8 @@ run on the fp32 MFMA kernels of conv.py; nothing here calls the library convolut
 """
 from __future__ import annotations
 
+import os as _os_env
+
 import torch
 
 from .fastfn import FastFunction
@@ -28,6 +30,33 @@ from .conv import SalunConv2d, _eligible
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
     """Logical NCHW tensor -> contiguous [N, H, W, C] bf16 view/copy."""
     return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+
+# SALUN_BF16_WGRAD_OVERLAP=0: backward-weight (+ its reduce and the bias column sums) on the main stream, as in rounds 2 - 5
+_OVERLAP_BF16 = [_os_env.environ.get("SALUN_BF16_WGRAD_OVERLAP", "1") != "0"]
+
+
+def _wgrad_beside(dev, tensors, launch):
+    """Weight / bias gradients that go straight into `.grad` (gradsink) are consumed by nothing before the end of the
+    backward pass: issue `launch()` on the side stream resblock.py keeps for exactly this (scratch buffers are per stream,
+    ops.workspace; the stream has a hardware queue of its own, streams.py), next to the input-gradient kernels of this and
+    the following layers — at batch 8 most of the SD U-Net's kernels leave CUs idle.  The main stream joins once, at the
+    end of the backward pass (or, under data parallel, where the gradient slice is reduced: dist.BucketedGradReducer)."""
+    from . import resblock
+    main, side = torch.cuda.current_stream(dev), resblock._side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = launch()
+    for t in tensors:
+        t.record_stream(side)
+    resblock.hold_until_join(tensors[-1])  # dy: autograd must not accumulate into it in place while the side stream reads it
+    resblock._join_at_end_of_backward(dev)
+    return out
+
+
+def _can_overlap() -> bool:
+    from . import resblock
+    return _OVERLAP_BF16[0] and resblock.OVERLAP_WGRAD and not torch.cuda.is_current_stream_capturing()
 
 
 class _ConvBF16Fn(FastFunction):
@@ -62,10 +91,15 @@ class _ConvBF16Fn(FastFunction):
             if ctx.nbias and ctx.needs_input_grad[4] and dyn.shape[0] <= 128:
                 # per-image channel sums of dy out of the bias gradient's partial sums (one kernel pair for both)
                 dnb = torch.empty((dyn.shape[0], w.shape[0]), dtype=torch.float32, device=dyn.device)
-            got = ops.conv2d_bf16_backward_weight(xn, dyn, tuple(w.shape), s, p, out=dst, accumulate=True, bias_out=bdst,
-                                                  nbias_out=dnb)
-            if dst is None:
-                dw = got
+            launch = lambda: ops.conv2d_bf16_backward_weight(xn, dyn, tuple(w.shape), s, p, out=dst, accumulate=True,
+                                                             bias_out=bdst, nbias_out=dnb)
+            # everything the call writes lands in .grad storage (dnb is read by autograd on this stream right away)
+            if dst is not None and db is None and dnb is None and _can_overlap():
+                _wgrad_beside(dyn.device, (xn, dyn), launch)
+            else:
+                got = launch()
+                if dst is None:
+                    dw = got
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_bf16_backward_data(dyn, mod.packed_weight(), tuple(xn.shape), R, s, p).permute(0, 3, 1, 2)
             if dx.dtype != ctx.x_dtype:
@@ -230,11 +264,15 @@ class _LinearBF16Fn(FastFunction):
             if ctx.has_bias and bdst is None:
                 bdst = torch.zeros(K, dtype=torch.float32, device=w.device)
                 db = bdst
-            got = ops.conv2d_bf16_backward_weight(as_img(x2, C), as_img(dy2, K), (K, C, 1, 1), 1, 0,
-                                                  out=dst.view(K, C, 1, 1) if dst is not None else None,
-                                                  accumulate=True, bias_out=bdst)
-            if dst is None:
-                dw = got.view(K, C)
+            launch = lambda: ops.conv2d_bf16_backward_weight(as_img(x2, C), as_img(dy2, K), (K, C, 1, 1), 1, 0,
+                                                             out=dst.view(K, C, 1, 1) if dst is not None else None,
+                                                             accumulate=True, bias_out=bdst)
+            if dst is not None and db is None and _can_overlap():
+                _wgrad_beside(dy2.device, (x2, dy2), launch)
+            else:
+                got = launch()
+                if dst is None:
+                    dw = got.view(K, C)
         if ctx.needs_input_grad[0]:
             if _USE_K16[0] and ops.gemm_bf16_supported(M, C, K) and _al16(dy2):
                 dx = ops.gemm_bf16_nt(dy2, mod.packed_weight_t(), None, None, _K16_VARIANT[0]).view(ctx.x_shape)

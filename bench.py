@@ -332,7 +332,7 @@ def sd_block(a):
         d = json.loads(lines[-1])
         return {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
                                   "mask_gen", "roofline", "fwd_bwd", "kernels", "host_enqueue_ms_per_step",
-                                  "cpu_baseline") if k in d}
+                                  "hbm_peak_alloc_GB", "resident_activations", "cpu_baseline") if k in d}
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -446,7 +446,7 @@ def main():
             import bench_ddpm
             return bench_ddpm.main(argv + (["--mask_batches", str(a.ddpm_mask_batches)] if a.no_mask_gen else []))
         import bench_sd
-        return bench_sd.main(argv + ["--bf16"])
+        return bench_sd.main(argv + ["--bf16", "--resident"])
     rank, local_rank, world = sdist.init_from_env()
     from unlearn_saliency_amd import _lib
     _lib.lib()  # fail loudly if the HIP extension is missing

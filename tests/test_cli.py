@@ -89,7 +89,7 @@ def test_sd_flags_and_defaults_match_reference(golden_dir, name):
             assert a.type is float and spec["type"] == "int"
         elif want is not None:
             assert a.type is want, (flag, a.type, want)
-    assert set(actions) - set(ref) == {"latents", "synthetic", "bf16"}
+    assert set(actions) - set(ref) == {"latents", "synthetic", "bf16", "resident_activations"}
 
 
 def test_sd_entry_points_refuse_without_a_gpu(tmp_path):

@@ -139,3 +139,42 @@ def test_certain_label_matches_plain_torch(tmp_path, method):
     if method == "xattn":
         sel = np.concatenate([np.full(s, "attn2" in k) for k, s in zip(names, sizes)])
         assert not moved[~sel].any() and moved[sel & (mflat == 1)].mean() > 0.9
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_resident_activations_give_the_checkpointed_gradient_bit_for_bit(bf16):
+    """unet.set_activation_checkpointing(False) (bench `resident_activations`, `--resident_activations` of the command
+    lines): the reference's config re-runs every block inside backward to save memory; keeping the activations instead
+    changes no kernel and no order of accumulation — the flat gradient of a remain + forget pass is identical."""
+    from unlearn_saliency_amd import ops
+    from unlearn_saliency_amd.SD import train_scripts as TS
+    from unlearn_saliency_amd.SD.ldm_lite import LatentDiffusionLite
+    from unlearn_saliency_amd.SD.unet import set_activation_checkpointing
+    cfg = dict(sd_tiny_config(), use_checkpoint=True)
+    m = LatentDiffusionLite(cfg, bf16=bf16)
+    fill_params(m.model.diffusion_model, 9100)
+    m = m.cuda()
+    m.use_mfma_convs()
+    arena = TS._unet_arena(m)
+    m.train()
+    (z_r, c_r), (z_f, c_f, c_p) = _batches(1, 500)[0], _batches(1, 600, with_pseudo=True)[0]
+    t = torch.tensor([5, 400, 77, 901], device="cuda")
+    noise = _t(rng.normal(4 * 4 * 8 * 8, 700).reshape(4, 4, 8, 8))
+
+    def grad():
+        arena.zero_grad()
+        with _Replay(11):
+            remain = m.shared_step({"z": z_r, "c": c_r})[0]
+        z_noisy = m.q_sample(x_start=z_f, t=t, noise=noise)
+        fo, po = TS.forget_and_target(m, z_noisy, t, c_f, c_p)
+        (ops.mse_loss(po, fo) + 0.1 * remain).backward()
+        torch.cuda.synchronize()
+        return arena.grads.clone()
+
+    g_ckpt = grad()
+    assert float(g_ckpt.abs().max()) > 0
+    assert set_activation_checkpointing(m.model.diffusion_model, False) > 0
+    g_res = grad()
+    assert torch.equal(g_ckpt, g_res)
+    assert set_activation_checkpointing(m.model.diffusion_model, True) > 0
+    assert torch.equal(grad(), g_ckpt)

@@ -129,6 +129,10 @@ def run(argv=None):
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--library_conv", action="store_true")
     ap.add_argument("--own_linear", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--resident", action="store_true",
+                    help="after the timed steps (the reference's configuration: activation checkpointing on) time the same "
+                         "steps once more with every activation kept in HBM (unet.set_activation_checkpointing(False): no "
+                         "recompute, identical results) and report it as `resident_activations`")
     ap.add_argument("--aten_origins", action="store_true",
                     help="diagnostic: one extra step under torch.profiler; the library (ATen) device kernels of the step "
                          "grouped by operator and the calling frames of this package go to stderr")
@@ -278,6 +282,39 @@ def run(argv=None):
                     "layer_norm_geglu": "K14 bf16 tokens" if a.bf16 else "library"},
         "hbm_peak_alloc_GB": torch.cuda.max_memory_allocated() / 1e9,
     }
+    if a.resident:
+        # the same loop with the activations resident: 3 forwards + 2 backwards, no recomputed forwards
+        from unlearn_saliency_amd.SD.unet import set_activation_checkpointing
+        n_blocks = set_activation_checkpointing(model.model.diffusion_model, False)
+        torch.cuda.reset_peak_memory_stats()
+        steps_(1)
+        torch.cuda.synchronize()
+        sdist.barrier()
+        gc.collect()
+        gc.disable()
+        t0 = time.perf_counter()
+        steps_(a.steps)
+        host_r = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        sdist.barrier()
+        dt_r = (time.perf_counter() - t0) / a.steps
+        gc.enable()
+        if world > 1:
+            t = torch.tensor([dt_r], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_r = float(t.item())
+        tflop_r = B * FWD_TFLOP_PER_SAMPLE * (3 + 4)
+        out["resident_activations"] = {
+            "value": world / dt_r, "unit": "steps/s", "ms_per_step": dt_r * 1e3,
+            "host_enqueue_ms_per_step": 1e3 * host_r / a.steps, "steps": a.steps, "blocks_switched": n_blocks,
+            "hbm_peak_alloc_GB": torch.cuda.max_memory_allocated() / 1e9,
+            "fwd_bwd": {"tflop_per_step": tflop_r, "achieved_TFLOPs": tflop_r / dt_r,
+                        "frac": tflop_r / dt_r / (2500.0 if a.bf16 else 157.3)},
+            "note": "same steps, same results (tests/test_sd_gpu.py: bit-identical parameters), activation checkpointing of "
+                    "the reference's v1-inference.yaml switched off: with 288 GB of HBM the ~50 GB of activations of a "
+                    "batch-8 step stay resident instead of being recomputed inside backward (3 fwd + 2 bwd = 7 "
+                    "forward-equivalents instead of 9).  `value` of this line stays the checkpointed configuration."}
+        set_activation_checkpointing(model.model.diffusion_model, True)
     if a.digest:
         import hashlib
         out["params_sha256"] = hashlib.sha256(arena.params.cpu().numpy().tobytes()).hexdigest()

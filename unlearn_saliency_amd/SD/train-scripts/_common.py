@@ -26,6 +26,9 @@ if ROOT not in sys.path:
 def add_batch_source_flags(parser):
     parser.add_argument("--latents", type=str, default=None, help="file with pre-encoded forget / remain batches")
     parser.add_argument("--synthetic", type=int, default=0, help="use this many synthetic batches instead")
+    parser.add_argument("--resident_activations", action="store_true",
+                        help="keep every activation in HBM instead of the config's activation checkpointing (use_checkpoint: "
+                             "True re-runs each block inside backward): identical results, no recompute; ~50 GB at batch 8")
     parser.add_argument("--bf16", action="store_true", help="bf16 configuration: bf16 NHWC MFMA convolutions, GroupNorm, attention, LayerNorm / GEGLU kernels (K11-K14), fp32 master weights")
 
 

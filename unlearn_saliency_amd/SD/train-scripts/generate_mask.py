@@ -33,7 +33,8 @@ def main(argv=None):
     classes = int(args.classes)
     device = _common.device_of(args.device)
     from unlearn_saliency_amd.SD import train_scripts as TS
-    model = TS.setup_model(args.config_path, args.ckpt_path, device, bf16=args.bf16)
+    model = TS.setup_model(args.config_path, args.ckpt_path, device, bf16=args.bf16,
+                           resident_activations=args.resident_activations)
     data = _common.batches(args, device, {"forget": 3}, model)
     if args.nsfw:
         TS.generate_nsfw_mask(args.c_guidance, args.batch_size, args.epochs, args.lr, args.config_path, args.ckpt_path,

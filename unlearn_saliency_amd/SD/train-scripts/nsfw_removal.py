@@ -37,7 +37,8 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     device = _common.device_of(str(args.device).split(",")[0])
     from unlearn_saliency_amd.SD import train_scripts as TS
-    model = TS.setup_model(args.config_path, args.ckpt_path, device, bf16=args.bf16)
+    model = TS.setup_model(args.config_path, args.ckpt_path, device, bf16=args.bf16,
+                           resident_activations=args.resident_activations)
     data = _common.batches(args, device, {"forget": 3, "remain": 2}, model)
     model, losses = TS.nsfw_removal(args.train_method, args.alpha, args.batch_size, args.epochs, args.lr, args.config_path,
                                     args.ckpt_path, args.mask_path, args.diffusers_config_path, device, args.image_size,

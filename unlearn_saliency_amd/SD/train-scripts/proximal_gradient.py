@@ -38,7 +38,8 @@ def main(argv=None):
     classes = int(args.class_to_forget)
     device = _common.device_of(args.device)
     from unlearn_saliency_amd.SD import train_scripts as TS
-    model = TS.setup_model(args.config_path, args.ckpt_path, device, bf16=args.bf16)
+    model = TS.setup_model(args.config_path, args.ckpt_path, device, bf16=args.bf16,
+                           resident_activations=args.resident_activations)
     data = _common.batches(args, device, {"forget": 3, "remain": 2}, model)
     model, losses = TS.proximal_gradient(classes, args.train_method, args.alpha, args.batch_size, args.epochs, args.lr,
                                          args.config_path, args.ckpt_path, args.mask_ratio, args.diffusers_config_path,

@@ -32,9 +32,10 @@ from .unet import V1_UNET_CONFIG
 
 UNET_PREFIX = "model.diffusion_model."
 
-def setup_model(config_path, ckpt_path, device, bf16=False) -> LatentDiffusionLite:
+def setup_model(config_path, ckpt_path, device, bf16=False, resident_activations=False) -> LatentDiffusionLite:
     """YAML (`model.params.unet_config.params`, e.g. configs/stable-diffusion/v1-inference.yaml) + optional CompVis
-    checkpoint (`state_dict` with `model.diffusion_model.*` keys).  No OmegaConf needed."""
+    checkpoint (`state_dict` with `model.diffusion_model.*` keys).  No OmegaConf needed.  `resident_activations`: ignore
+    the config's `use_checkpoint` and keep every activation in HBM (unet.set_activation_checkpointing)."""
     cfg = dict(V1_UNET_CONFIG)
     if config_path and os.path.exists(config_path):
         with open(config_path) as f:
@@ -48,6 +49,9 @@ def setup_model(config_path, ckpt_path, device, bf16=False) -> LatentDiffusionLi
         model.model.diffusion_model.load_state_dict(unet_sd, strict=True)
     if torch.device(device).type == "cuda":
         model.use_mfma_convs()
+    if resident_activations:
+        from .unet import set_activation_checkpointing
+        set_activation_checkpointing(model.model.diffusion_model, False)
     return model
 
 

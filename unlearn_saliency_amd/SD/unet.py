@@ -327,6 +327,24 @@ class UNetModel(nn.Module):
         return self.out[2](fused_gn_act(h.type(x.dtype), self.out[0], silu=True))
 
 
+def set_activation_checkpointing(model: nn.Module, enabled: bool) -> int:
+    """Flip `use_checkpoint` on every block of a built U-Net; returns how many blocks changed.  The reference's
+    v1-inference.yaml turns activation checkpointing on (`use_checkpoint: True`,
+    SD/ldm/modules/diffusionmodules/openaimodel.py:245-247, attention.py:209-210): every ResBlock / transformer block is
+    run a second time inside the backward pass so that its activations need not be kept — a device of 24 – 80 GB-class
+    accelerators.  At batch 8 the whole step keeps ~50 GB of activations; with 288 GB of HBM they can simply stay
+    resident (`enabled = False`): same kernels on the same inputs in the same order for everything that is kept,
+    bit-identical parameters after the step (tests/test_sd_gpu.py), two of the nine forward-equivalents of a
+    nsfw_removal step gone."""
+    n = 0
+    for m in model.modules():
+        if isinstance(m, (ResBlock, BasicTransformerBlock, SpatialTransformer, UNetModel)) and hasattr(m, "use_checkpoint"):
+            if bool(m.use_checkpoint) != bool(enabled):
+                m.use_checkpoint = bool(enabled)
+                n += 1
+    return n
+
+
 V1_UNET_CONFIG = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1),
                       num_res_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8, use_spatial_transformer=True,
                       transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)

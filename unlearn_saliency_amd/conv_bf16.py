@@ -67,31 +67,32 @@ class _ConvBF16Fn(FastFunction):
         wp = mod.packed_weight()
         an = _nhwc(addend) if addend is not None else None
         y = ops.conv2d_bf16_forward(xn, wp, R, s, p, bias=bias, nbias=nbias, addend=an)
-        ctx.save_for_backward(xn, w)
+        ctx.save_for_backward(xn)  # (the weight is reached through `mod`: no saved-tensor hook for it, norm._FusedGN16)
+        ctx.w_shape = tuple(w.shape)
         ctx.mod, ctx.has_bias, ctx.x_dtype = mod, bias is not None, x.dtype
         ctx.nbias, ctx.addend_dtype = nbias is not None, (addend.dtype if addend is not None else None)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dy):
-        xn, w = ctx.saved_tensors
-        mod = ctx.mod
+        xn, = ctx.saved_tensors
+        mod, wshape = ctx.mod, ctx.w_shape
         R, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
         dyn = _nhwc(dy)
         dx = dw = db = dnb = dadd = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dst = gradsink.sink(mod.weight)  # the Parameter itself: `w` from saved_tensors is a detached alias under checkpointing
+            dst = gradsink.sink(mod.weight)  # the Parameter itself
             # the kernel has ONE accumulate flag for dw and db: without a weight sink it overwrites both outputs, so
             # the bias gradient must not target bias.grad then (it would be overwritten, not accumulated) — it goes
             # through autograd like dw; with a weight sink but no bias sink, db accumulates into fresh zeros
             bdst = gradsink.sink(mod.bias) if (ctx.has_bias and dst is not None) else None
             if ctx.has_bias and bdst is None:
-                bdst = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+                bdst = torch.zeros(wshape[0], dtype=torch.float32, device=dyn.device)
                 db = bdst
             if ctx.nbias and ctx.needs_input_grad[4] and dyn.shape[0] <= 128:
                 # per-image channel sums of dy out of the bias gradient's partial sums (one kernel pair for both)
-                dnb = torch.empty((dyn.shape[0], w.shape[0]), dtype=torch.float32, device=dyn.device)
-            launch = lambda: ops.conv2d_bf16_backward_weight(xn, dyn, tuple(w.shape), s, p, out=dst, accumulate=True,
+                dnb = torch.empty((dyn.shape[0], wshape[0]), dtype=torch.float32, device=dyn.device)
+            launch = lambda: ops.conv2d_bf16_backward_weight(xn, dyn, wshape, s, p, out=dst, accumulate=True,
                                                              bias_out=bdst, nbias_out=dnb)
             # everything the call writes lands in .grad storage (dnb is read by autograd on this stream right away)
             if dst is not None and db is None and dnb is None and _can_overlap():
@@ -244,16 +245,17 @@ class _LinearBF16Fn(FastFunction):
             xn = x2.view(1, M // 8, 8, C) if M % 8 == 0 else x2.view(1, M, 1, C)
             an = a2.view(1, xn.shape[1], xn.shape[2], K) if a2 is not None else None
             y = ops.conv2d_bf16_forward(xn, mod.packed_weight(), 1, 1, 0, bias=bias, nbias=None, addend=an)
-        ctx.save_for_backward(x2, w)
+        ctx.save_for_backward(x2)
+        ctx.w_shape = (K, C)
         ctx.mod, ctx.has_bias, ctx.x_shape, ctx.x_dtype = mod, bias is not None, tuple(x.shape), x.dtype
         ctx.addend_dtype = addend.dtype if addend is not None else None
         return y.view(*x.shape[:-1], K)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
+        x2, = ctx.saved_tensors
         mod = ctx.mod
-        K, C = w.shape
+        K, C = ctx.w_shape
         M = x2.shape[0]
         dy2 = dy.to(torch.bfloat16).contiguous().view(M, K)
         as_img = lambda t, ch: t.view(1, M // 8, 8, ch) if M % 8 == 0 else t.view(1, M, 1, ch)
@@ -262,7 +264,7 @@ class _LinearBF16Fn(FastFunction):
             dst = gradsink.sink(mod.weight)
             bdst = gradsink.sink(mod.bias) if (ctx.has_bias and dst is not None) else None
             if ctx.has_bias and bdst is None:
-                bdst = torch.zeros(K, dtype=torch.float32, device=w.device)
+                bdst = torch.zeros(K, dtype=torch.float32, device=dy2.device)
                 db = bdst
             launch = lambda: ops.conv2d_bf16_backward_weight(as_img(x2, C), as_img(dy2, K), (K, C, 1, 1), 1, 0,
                                                              out=dst.view(K, C, 1, 1) if dst is not None else None,

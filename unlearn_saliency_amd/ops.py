@@ -761,14 +761,15 @@ class _LayerNorm16(FastFunction):
                                                _dev(bias, torch.float32, "beta"), c_void_p(y.data_ptr()),
                                                c_void_p(stats.data_ptr()), c_int64(rows), C, c_double(eps), _stream()),
               "salun_ln_bf16_forward")
-        ctx.save_for_backward(xc, weight, bias, stats)
-        ctx.params = (weight, bias)  # Parameter objects for gradsink (saved_tensors are detached aliases under checkpointing)
-        return y
+        ctx.save_for_backward(xc, stats)
+        ctx.params = (weight, bias)  # the Parameter objects: gradsink's destinations, and gamma's values in backward (plain
+        return y                     # references instead of saved tensors: norm._FusedGN16 says why)
 
     @staticmethod
     def backward(ctx, dy):
         from . import gradsink
-        xc, weight, bias, stats = ctx.saved_tensors
+        xc, stats = ctx.saved_tensors
+        weight, bias = ctx.params
         C = xc.shape[-1]
         rows = xc.numel() // C
         dyc = dy.to(torch.bfloat16).contiguous()

@@ -43,10 +43,13 @@ def _wgrad_beside(dev, tensors, launch):
     the following layers — at batch 8 most of the SD U-Net's kernels leave CUs idle.  The main stream joins once, at the
     end of the backward pass (or, under data parallel, where the gradient slice is reduced: dist.BucketedGradReducer)."""
     from . import resblock
-    main, side = torch.cuda.current_stream(dev), resblock._side_stream(dev)
+    main, side = torch.cuda.current_stream(dev.index), resblock._side_stream(dev)
     side.wait_stream(main)
-    with torch.cuda.stream(side):
+    ops._STREAM_OVERRIDE[0] = side.cuda_stream  # instead of `with torch.cuda.stream(side)`: see ops._STREAM_OVERRIDE
+    try:
         out = launch()
+    finally:
+        ops._STREAM_OVERRIDE[0] = None
     for t in tensors:
         t.record_stream(side)
     resblock.hold_until_join(tensors[-1])  # dy: autograd must not accumulate into it in place while the side stream reads it

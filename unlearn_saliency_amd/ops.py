@@ -21,10 +21,20 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+# Set (to a raw stream handle) around calls that must be issued on another stream than torch's current one WITHOUT paying
+# for `with torch.cuda.stream(...)` (~10 us of host time per use; conv_bf16._wgrad_beside issues 470 backward-weight calls
+# per SD step on the side stream and the step is host-bound).  Only the wrappers of this module look at it: a wrapper
+# that allocates its result with torch must not be called under an override (the allocation would belong to the current
+# stream) — backward-weight into `.grad` storage allocates nothing but the per-stream scratch buffer.
+_STREAM_OVERRIDE = [None]
+
+
 def _stream_handle(idx: Optional[int] = None) -> int:
     """The raw handle of device `idx`'s (default: the current device's) current stream — what
     `torch.cuda.current_stream(idx).cuda_stream` returns, without building a Stream object and re-probing the device on
     each of ~4,500 calls per SD step."""
+    if _STREAM_OVERRIDE[0] is not None:
+        return _STREAM_OVERRIDE[0]
     if _raw_stream is None or _cur_device is None:
         return torch.cuda.current_stream(idx).cuda_stream
     return _raw_stream(_cur_device() if idx is None else idx)
@@ -46,6 +56,21 @@ def _dev(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, allow_none: b
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
     return c_void_p(t.data_ptr())
+
+
+# Shape-only queries of the library (workspace sizes, "is this shape in the kernel's domain") memoised on the host: each is
+# a ctypes round trip, and the SD step — host-bound since round 6 — asked ~3,000 of them per step with a few dozen
+# distinct argument tuples.
+_shape_memo: dict = {}
+
+
+def _q(name: str, *args):
+    key = (name,) + args
+    v = _shape_memo.get(key)
+    if v is None:
+        fn = getattr(_lib.lib(), name)
+        v = _shape_memo[key] = fn(*[c_int64(a) if t is c_int64 else a for a, t in zip(args, fn.argtypes)])
+    return v
 
 
 # One scratch buffer per (device, stream), grown on demand: reuse is ordered by the stream the kernels run on, so
@@ -491,7 +516,7 @@ def channel_sum(dy: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate
 # ----------------------------------------------------------------------------- K11
 # bf16 NHWC convolution on the bf16 matrix-core instruction; tensors are [N, H, W, C] contiguous bfloat16.
 def conv2d_bf16_supported(C: int, K: int, R: int, stride: int, pad: int) -> bool:
-    return bool(_lib.lib().salun_conv2d_bf16_supported(C, K, R, stride, pad))
+    return bool(_q("salun_conv2d_bf16_supported", C, K, R, stride, pad))
 
 
 # number of weight re-packs issued so far (SD/train_scripts.py::forget_and_target uses it to detect cold caches: a pack
@@ -540,7 +565,7 @@ def conv2d_bf16_forward(x: torch.Tensor, wp: torch.Tensor, R: int, stride: int, 
     OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
     _dev(x, torch.bfloat16, "x")  # device / dtype / layout errors before anything touches the device
     y = torch.empty((N, OH, OW, K), dtype=torch.bfloat16, device=x.device)
-    ws = workspace(_lib.lib().salun_conv2d_bf16_data_workspace_bytes(N, H, W, C, K, R, stride, pad), x.device)
+    ws = workspace(_q("salun_conv2d_bf16_data_workspace_bytes", N, H, W, C, K, R, stride, pad), x.device)
     check(_lib.lib().salun_conv2d_bf16_forward(_dev(x, torch.bfloat16, "x"), _dev(wp, torch.bfloat16, "wp"),
                                                _dev(bias, torch.float32, "bias", True),
                                                _dev(nbias, torch.float32, "nbias", True),
@@ -556,7 +581,7 @@ def conv2d_bf16_backward_data(dy: torch.Tensor, wp: torch.Tensor, x_shape, R: in
     K = wp.shape[0]
     _dev(dy, torch.bfloat16, "dy")
     dx = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
-    ws = workspace(_lib.lib().salun_conv2d_bf16_data_workspace_bytes(N, H, W, C, K, R, stride, pad), dy.device)
+    ws = workspace(_q("salun_conv2d_bf16_data_workspace_bytes", N, H, W, C, K, R, stride, pad), dy.device)
     check(_lib.lib().salun_conv2d_bf16_backward_data(_dev(dy, torch.bfloat16, "dy"), _dev(wp, torch.bfloat16, "wp"),
                                                      _dev(addend, torch.bfloat16, "addend", True),
                                                      c_void_p(dx.data_ptr()), N, H, W, C, K, R, stride, pad,
@@ -575,7 +600,7 @@ def conv2d_bf16_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stri
     N, H, W, C = x.shape
     K, _, R, _ = w_shape
     L = _lib.lib()
-    nbytes = L.salun_conv2d_bf16_wgrad_workspace_bytes(N, H, W, C, K, R, stride, pad)
+    nbytes = _q("salun_conv2d_bf16_wgrad_workspace_bytes", N, H, W, C, K, R, stride, pad)
     if nbytes == 0:
         raise ValueError(f"bf16 backward-weight: unsupported shape C={C} K={K} R={R} stride={stride} pad={pad}")
     ws = workspace(nbytes, x.device)
@@ -593,7 +618,7 @@ def conv2d_bf16_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stri
 
 # ----------------------------------------------------------------------------- K16
 def gemm_bf16_supported(M: int, N: int, K: int) -> bool:
-    return bool(_lib.lib().salun_gemm_bf16_supported(c_int64(M), int(N), int(K)))
+    return bool(_q("salun_gemm_bf16_supported", int(M), int(N), int(K)))
 
 
 def gemm_bf16_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -649,7 +674,7 @@ def gn_bf16_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gr
     """x [N, H, W, C] bf16 contiguous -> (y, mr, ab): y = [silu](GroupNorm(x)); mr / ab feed gn_bf16_backward."""
     N, H, W, C = x.shape
     L = _lib.lib()
-    ws = workspace(L.salun_gn_bf16_workspace_bytes(N, C, H * W, groups), x.device)
+    ws = workspace(_q("salun_gn_bf16_workspace_bytes", N, C, H * W, groups), x.device)
     y = torch.empty_like(x)
     mr = torch.empty((N, groups, 2), dtype=torch.float32, device=x.device)
     ab = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
@@ -664,7 +689,7 @@ def gn_bf16_backward(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mr:
                      groups: int, silu: bool, dgamma: torch.Tensor, dbeta: torch.Tensor, accumulate: bool) -> torch.Tensor:
     N, H, W, C = x.shape
     L = _lib.lib()
-    ws = workspace(L.salun_gn_bf16_workspace_bytes(N, C, H * W, groups), x.device)
+    ws = workspace(_q("salun_gn_bf16_workspace_bytes", N, C, H * W, groups), x.device)
     dx = torch.empty_like(x)
     check(L.salun_gn_bf16_backward(_dev(dy, torch.bfloat16, "dy"), _dev(x, torch.bfloat16, "x"),
                                    _dev(gamma, torch.float32, "gamma"), _dev(mr, torch.float32, "mr"),
@@ -677,7 +702,7 @@ def gn_bf16_backward(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mr:
 
 # ----------------------------------------------------------------------------- K13
 def attn_supported(D: int) -> bool:
-    return bool(_lib.lib().salun_attn_supported(int(D)))
+    return bool(_q("salun_attn_supported", int(D)))
 
 
 def _tok_view(t: torch.Tensor, name: str):
@@ -774,7 +799,7 @@ class _LayerNorm16(FastFunction):
         rows = xc.numel() // C
         dyc = dy.to(torch.bfloat16).contiguous()
         L = _lib.lib()
-        ws = workspace(L.salun_ln_bf16_workspace_bytes(c_int64(rows), C), xc.device)
+        ws = workspace(_q("salun_ln_bf16_workspace_bytes", rows, C), xc.device)
         gw, gb = gradsink.sink(ctx.params[0]), gradsink.sink(ctx.params[1])
         sunk = gw is not None and gb is not None
         if not sunk:

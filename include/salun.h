@@ -375,6 +375,13 @@ int salun_conv2d_bf16_backward_weight(const uint16_t *x /*dev*/, const uint16_t 
  * gradient of the forward's `nbias[n][k]` term (a ResBlock's time-embedding projection,
  * SD/ldm/modules/diffusionmodules/openaimodel.py:249-263: `h = h + emb_out[..., None, None]`), from the partial sums the
  * bias gradient is folded from anyway (no fp32 copy of dy, no separate reduction).  db may be NULL then. */
+/* The column sums of dy[M][K] (bf16) alone: db[K] (fp32, = or +=; or NULL) and / or dnb[images][K] (fp32, overwritten; or
+ * NULL; M = images * pixels, images <= 128) — what the two calls above fold next to dw; for callers that want the
+ * per-image sums on another stream than the weight gradient (conv_bf16.py: backward-weight on the side stream, the
+ * time-embedding gradient on the compute stream). */
+size_t salun_colsum_bf16_workspace_bytes(int K);
+int salun_colsum_bf16(const uint16_t *dy /*dev*/, float *db /*dev or NULL*/, float *dnb /*dev or NULL*/, int64_t M, int K,
+                      int images, int accumulate, void *ws /*dev*/, size_t ws_bytes, salun_stream_t stream);
 int salun_conv2d_bf16_backward_weight_ex(const uint16_t *x /*dev*/, const uint16_t *dy /*dev*/, float *dw /*dev*/,
                                          float *db /*dev or NULL*/, float *dnb /*dev or NULL*/, int N, int H, int W, int C,
                                          int K, int R, int stride, int pad, int accumulate, void *ws /*dev*/,

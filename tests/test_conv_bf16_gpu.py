@@ -236,6 +236,13 @@ def test_per_image_channel_sums_ride_on_the_bias_gradient(dims):
     dnb3 = torch.empty((N, K), device="cuda")
     ops.conv2d_bf16_backward_weight(x, dy, (K, C, R, R), 1, pad, nbias_out=dnb3)
     assert torch.equal(dnb3, dnb)
+    # the sums alone (salun_colsum_bf16): the same kernels, the same numbers
+    dnb4, db4 = torch.empty((N, K), device="cuda"), torch.ones(K, device="cuda")
+    ops.colsum_bf16(dy, N, bias_out=db4, nbias_out=dnb4, accumulate=True)
+    assert torch.equal(dnb4, dnb) and torch.equal(db4, acc)
+    db5 = torch.empty(K, device="cuda")
+    ops.colsum_bf16(dy, N, bias_out=db5)
+    assert torch.equal(db5, db0)
 
 
 def test_resblock_time_embedding_gradient_through_the_fused_sums():
@@ -243,11 +250,13 @@ def test_resblock_time_embedding_gradient_through_the_fused_sums():
     from a copy of dy before round 6), weights trainable or frozen."""
     from unlearn_saliency_amd import conv_bf16
     torch.manual_seed(3)
-    for frozen in (False, True):
+    for frozen, sunk in ((False, False), (True, False), (False, True)):
         conv = torch.nn.Conv2d(64, 96, 3, padding=1).cuda()
         conv.__class__ = conv_bf16.SalunConv2dBF16
         conv.weight.requires_grad_(not frozen)
         conv.bias.requires_grad_(not frozen)
+        if sunk:  # gradients go straight into .grad: backward-weight on the side stream, the sums on this one
+            conv.weight.grad, conv.bias.grad = torch.zeros_like(conv.weight), torch.zeros_like(conv.bias)
         x = torch.randn(4, 64, 16, 16, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         emb = torch.randn(4, 96, device="cuda", requires_grad=True)
         y = conv(x, nbias=emb)
@@ -255,3 +264,7 @@ def test_resblock_time_embedding_gradient_through_the_fused_sums():
         y.backward(dy)
         ref = dy.float().sum(dim=(2, 3))
         assert float((emb.grad - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        if sunk:
+            torch.cuda.synchronize()
+            assert float((conv.bias.grad - ref.sum(0)).abs().max()) <= 1e-5 * float(ref.sum(0).abs().max() + ref.abs().max())
+            assert float(conv.weight.grad.abs().max()) > 0

@@ -114,6 +114,8 @@ SIGNATURES = {
     "salun_conv2d_bf16_backward_data": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_bf16_wgrad_workspace_bytes": (c_size_t, [c_int] * 8),
     "salun_conv2d_bf16_backward_weight": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
+    "salun_colsum_bf16_workspace_bytes": (c_size_t, [c_int]),
+    "salun_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "salun_conv2d_bf16_backward_weight_ex": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
     "salun_gn_bf16_workspace_bytes": (c_size_t, [c_int] * 4),
     "salun_gn_bf16_forward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_double, c_int, c_void_p, c_size_t, c_void_p]),

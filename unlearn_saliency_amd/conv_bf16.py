@@ -95,13 +95,17 @@ class _ConvBF16Fn(FastFunction):
             if ctx.nbias and ctx.needs_input_grad[4] and dyn.shape[0] <= 128:
                 # per-image channel sums of dy out of the bias gradient's partial sums (one kernel pair for both)
                 dnb = torch.empty((dyn.shape[0], wshape[0]), dtype=torch.float32, device=dyn.device)
-            launch = lambda: ops.conv2d_bf16_backward_weight(xn, dyn, wshape, s, p, out=dst, accumulate=True,
-                                                             bias_out=bdst, nbias_out=dnb)
-            # everything the call writes lands in .grad storage (dnb is read by autograd on this stream right away)
-            if dst is not None and db is None and dnb is None and _can_overlap():
-                _wgrad_beside(dyn.device, (xn, dyn), launch)
+            if dst is not None and db is None and _can_overlap():
+                # everything the backward-weight call writes lands in .grad storage: side stream; dnb is read by autograd
+                # on THIS stream right away, so its (small) sums are a launch of their own here
+                if dnb is not None:
+                    ops.colsum_bf16(dyn, dyn.shape[0], nbias_out=dnb)
+                _wgrad_beside(dyn.device, (xn, dyn),
+                              lambda: ops.conv2d_bf16_backward_weight(xn, dyn, wshape, s, p, out=dst, accumulate=True,
+                                                                      bias_out=bdst))
             else:
-                got = launch()
+                got = ops.conv2d_bf16_backward_weight(xn, dyn, wshape, s, p, out=dst, accumulate=True, bias_out=bdst,
+                                                      nbias_out=dnb)
                 if dst is None:
                     dw = got
         if ctx.needs_input_grad[0]:

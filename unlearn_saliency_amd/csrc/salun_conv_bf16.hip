@@ -1146,6 +1146,15 @@ SALUN_EXPORT int salun_conv2d_bf16_backward_weight_ex(const uint16_t *x, const u
   return SALUN_OK;
 }
 
+// The column sums alone: db[K] (=, += or NULL) and / or dnb[images][K] of dy[M][K] (M = images * pixels per image).
+SALUN_EXPORT size_t salun_colsum_bf16_workspace_bytes(int K) { return K < 8 ? 0 : (size_t)COLSUM_CHUNKS * K * sizeof(float); }
+SALUN_EXPORT int salun_colsum_bf16(const uint16_t *dy, float *db, float *dnb, int64_t M, int K, int images, int accumulate,
+                                   void *ws, size_t ws_bytes, salun_stream_t stream) {
+  if (!dy || (!db && !dnb) || !ws || M < 1 || K < 8 || K % 8 || images < 1 || !salun_aligned16(dy)) return SALUN_EINVAL;
+  if (ws_bytes < salun_colsum_bf16_workspace_bytes(K)) return SALUN_ENOSPC;
+  return launch_colsum(dy, static_cast<float *>(ws), db, dnb, M, K, images, accumulate, salun_hip_stream(stream));
+}
+
 SALUN_EXPORT int salun_conv2d_bf16_backward_weight(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N,
                                                    int H, int W, int C, int K, int R, int stride, int pad, int accumulate,
                                                    void *ws, size_t ws_bytes, salun_stream_t stream) {

@@ -616,6 +616,19 @@ def conv2d_bf16_backward_weight(x: torch.Tensor, dy: torch.Tensor, w_shape, stri
     return dw
 
 
+def colsum_bf16(dy: torch.Tensor, images: int, bias_out: Optional[torch.Tensor] = None,
+                nbias_out: Optional[torch.Tensor] = None, accumulate: bool = False) -> None:
+    """dy bf16 [..., K] contiguous (rows = images x pixels): bias_out[K] (=, or += with accumulate) and / or
+    nbias_out[images, K] (overwritten) receive its column sums / per-image column sums (fp32)."""
+    K = dy.shape[-1]
+    M = dy.numel() // K
+    ws = workspace(_q("salun_colsum_bf16_workspace_bytes", K), dy.device)
+    check(_lib.lib().salun_colsum_bf16(_dev(dy, torch.bfloat16, "dy"), _dev(bias_out, torch.float32, "db", True),
+                                       _dev(nbias_out, torch.float32, "dnb", True), c_int64(M), K, int(images),
+                                       int(bool(accumulate)), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), _stream()),
+          "salun_colsum_bf16")
+
+
 # ----------------------------------------------------------------------------- K16
 def gemm_bf16_supported(M: int, N: int, K: int) -> bool:
     return bool(_q("salun_gemm_bf16_supported", int(M), int(N), int(K)))

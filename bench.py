@@ -319,6 +319,24 @@ def dp_ws1_line(extra, plain_ms):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def dp_ws1_checked(extra, plain_ms):
+    """dp_ws1_line, run a second time when the first reading is more than 15 % above the single-process step: one default run
+    of round 6 read 1.50x for ResNet-18 on a box whose host legs were all 20 - 50 % slow, ten others 1.015 - 1.022x.  Both
+    readings stay in the block (`attempts_ms`); the fields are the faster one's."""
+    first = dp_ws1_line(extra, plain_ms)
+    if "error" in first or not first.get("dp_over_plain") or first["dp_over_plain"] <= 1.15:
+        return first
+    second = dp_ws1_line(extra, plain_ms)
+    if "error" in second:
+        first["second_attempt_error"] = second["error"]
+        return first
+    best = min((first, second), key=lambda r: r["ms_per_step"])
+    best = dict(best)
+    best["attempts_ms"] = [first["ms_per_step"], second["ms_per_step"]]
+    best["note"] = "first reading > 1.15x the single-process step: measured twice, both readings in attempts_ms, fields = the faster"
+    return best
+
+
 def sd_block(a):
     """`bench.py --workload sd --gpus 1` (bf16, batch 8) in a subprocess; its line's fields that matter."""
     import subprocess
@@ -697,9 +715,9 @@ def main():
             if not a.no_dp:
                 # the data-parallel path at world size 1 (the N > 1 step is not the N = 1 step — other
                 # stream schedule, gradient slices through RCCL): same workloads, short windows, one subprocess each
-                out["dp_ws1"] = {"resnet18": dp_ws1_line(["--steps", "60", "--warmup", "10", "--no_mask_gen"],
+                out["dp_ws1"] = {"resnet18": dp_ws1_checked(["--steps", "60", "--warmup", "10", "--no_mask_gen"],
                                                          out["ms_per_step"]),
-                                 "ddpm": dp_ws1_line(["--workload", "ddpm", "--steps", "8", "--warmup", "3",
+                                 "ddpm": dp_ws1_checked(["--workload", "ddpm", "--steps", "8", "--warmup", "3",
                                                       "--no_mask_gen", "--ddpm_mask_batches", "2"],
                                                      out.get("ddpm", {}).get("ms_per_step")),
                                  "note": "`bench.py --gpus 1 --force_collectives ...`: process group over RCCL with one "
@@ -707,7 +725,7 @@ def main():
                                          "backward, the fused update waits for them; `plain_ms_per_step` is this "
                                          "line's single-process figure for the same workload"}
                 if not a.no_sd:
-                    out["dp_ws1"]["sd"] = dp_ws1_line(["--workload", "sd", "--steps", "3", "--warmup", "1"],
+                    out["dp_ws1"]["sd"] = dp_ws1_checked(["--workload", "sd", "--steps", "3", "--warmup", "1"],
                                                       out.get("sd", {}).get("ms_per_step"))
         print(json.dumps(out), flush=True)
     sdist.barrier()

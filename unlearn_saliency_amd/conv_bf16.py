@@ -129,8 +129,7 @@ import weakref as _weakref
 
 _REGISTERED: list = []      # weak references, in registration order (the order of use in a forward pass)
 _IS_REGISTERED = "_salun_pack_registered"
-import os as _os0
-BATCH_PACKS = [_os0.environ.get("SALUN_BF16_BATCH_PACK", "1") != "0"]  # A/B switch: False = one launch per image at its first use
+BATCH_PACKS = [_os_env.environ.get("SALUN_BF16_BATCH_PACK", "1") != "0"]  # A/B switch: False = one launch per image at its first use
 PACK_LAUNCHES = [0]
 
 

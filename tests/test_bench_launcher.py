@@ -69,3 +69,21 @@ def test_strong_scaling_keeps_the_reference_global_batch():
     assert out["forget"] == "random" and len(out["forget_classes"]) == 10
     assert out["global_batch"] == 256 and out["forget_batches"] == 18   # the reference's 18 forget batches per epoch
     assert out["shards_partition_every_batch"] and out["tail_batch"] == [74, 74]
+
+
+def test_outlier_data_parallel_reading_is_measured_twice(monkeypatch):
+    """bench.dp_ws1_checked: a reading more than 15 % above the single-process step is repeated; both stay in the block."""
+    import importlib, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    readings = iter([{"ms_per_step": 12.9, "dp_over_plain": 1.5}, {"ms_per_step": 8.7, "dp_over_plain": 1.01}])
+    monkeypatch.setattr(bench, "dp_ws1_line", lambda extra, plain: dict(next(readings)))
+    r = bench.dp_ws1_checked([], 8.6)
+    assert r["ms_per_step"] == 8.7 and r["attempts_ms"] == [12.9, 8.7] and "note" in r
+    calls = []
+    monkeypatch.setattr(bench, "dp_ws1_line", lambda extra, plain: calls.append(1) or {"ms_per_step": 8.8, "dp_over_plain": 1.02})
+    r = bench.dp_ws1_checked([], 8.6)
+    assert len(calls) == 1 and "attempts_ms" not in r
+    monkeypatch.setattr(bench, "dp_ws1_line", lambda extra, plain: {"error": "x"})
+    assert bench.dp_ws1_checked([], 8.6) == {"error": "x"}

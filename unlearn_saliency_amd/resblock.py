@@ -30,6 +30,7 @@ from . import draws, gradsink, ops, streams
 # on a side stream lets the two kernels share the CUs — the matrix pipes idle less than when either runs alone.
 # SALUN_WGRAD_OVERLAP=0 keeps everything on one stream.
 OVERLAP_WGRAD = os.environ.get("SALUN_WGRAD_OVERLAP", "1") != "0"
+FWD_SHORTCUT_BESIDE = os.environ.get("SALUN_FWD_SHORTCUT_BESIDE", "1") != "0"  # _BasicBlockFn.forward
 
 
 class overlap_disabled:
@@ -131,16 +132,33 @@ class _BasicBlockFn(FastFunction):
         N, C, H, W = x.shape
         P, Q = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
         training = blk.bn1.training
+        cd = md = idd = None
+        fork = None
+        if wd is not None:
+            def shortcut():
+                cd_ = ops.conv2d_forward(x, wd, None, s, 0, P, Q)
+                return (cd_,) + tuple(ops.bn_forward(cd_, None, gd, bd, *_bn_args(blk.downsample[1]), False,
+                                                     blk.downsample[1].num_batches_tracked))
+            if FWD_SHORTCUT_BESIDE and OVERLAP_WGRAD and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+                # the 1x1 stride-2 projection + its BatchNorm depend on x alone: issued on the (idle, in forward)
+                # backward-weight side stream beside conv1 -> bn1 -> conv2, joined before bn2 adds the result
+                main, fork = torch.cuda.current_stream(x.device), _side_stream(x.device)
+                fork.wait_stream(main)
+                with torch.cuda.stream(fork):
+                    cd, skip, md, idd = shortcut()
+                x.record_stream(fork)
         c1 = ops.conv2d_forward(x, w1, None, s, 1, P, Q)
         y1, m1, i1 = ops.bn_forward(c1, None, g1, b1, *_bn_args(blk.bn1), True, blk.bn1.num_batches_tracked)
         c2 = ops.conv2d_forward(y1, w2, None, 1, 1, P, Q)
-        cd = md = idd = None
-        if wd is not None:
-            cd = ops.conv2d_forward(x, wd, None, s, 0, P, Q)
-            skip, md, idd = ops.bn_forward(cd, None, gd, bd, *_bn_args(blk.downsample[1]), False,
-                                           blk.downsample[1].num_batches_tracked)
-        else:
+        if wd is None:
             skip = x
+        elif fork is None:
+            cd, skip, md, idd = shortcut()
+        else:
+            main.wait_stream(fork)
+            for t in (cd, skip, md, idd):  # allocated under the side stream, used (and freed) on this one from here on
+                if t is not None:
+                    t.record_stream(main)
         out, m2, i2 = ops.bn_forward(c2, skip, g2, b2, *_bn_args(blk.bn2), True, blk.bn2.num_batches_tracked)
         ctx.save_for_backward(x, c1, y1, c2, out, cd, w1, g1, b1, w2, g2, b2, wd, gd, bd, m1, i1, m2, i2, md, idd)
         ctx.cfg = (s, training)

@@ -227,3 +227,32 @@ def test_validate_accuracy():
         hits = sum(int((model(torch.from_numpy(x).cuda()).argmax(1).cpu() == torch.from_numpy(y)).sum())
                    for x, y in batches)
     assert abs(acc - 100.0 * hits / 48) < 1e-9
+
+
+def test_projection_branch_beside_the_main_chain_changes_nothing():
+    """resblock._BasicBlockFn.forward issues the 1x1 stride-2 projection + its BatchNorm of a strided block on the side
+    stream (round 6): outputs, running statistics and every gradient are bit-identical to the one-stream order."""
+    import torch
+    from unlearn_saliency_amd import resblock
+    from unlearn_saliency_amd.Classification.models import resnet_cifar
+    from unlearn_saliency_amd.conv import use_salun_convs
+
+    def run(flag):
+        torch.manual_seed(7)
+        net = resnet_cifar.resnet18(num_classes=10).cuda()
+        use_salun_convs(net)
+        net.train()
+        x = torch.randn(64, 3, 32, 32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+        old = resblock.FWD_SHORTCUT_BESIDE
+        resblock.FWD_SHORTCUT_BESIDE = flag
+        try:
+            y = net(x)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            resblock.FWD_SHORTCUT_BESIDE = old
+        bufs = [b.clone() for b in net.buffers()]
+        return [y.detach().clone()] + [p.grad.clone() for p in net.parameters()] + bufs
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) and all(torch.equal(u, v) for u, v in zip(a, b))

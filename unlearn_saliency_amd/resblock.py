@@ -8,6 +8,9 @@ the residual branch's gradient is folded into conv1's backward-data epilogue (`a
 add pass over the activation, and all weight / BN gradients are accumulated by their kernels directly into the
 parameters' `.grad` storage (gradsink.py) — no AccumulateGrad launches.  Per block that removes one
 3-pass elementwise add over the block input and 6-9 small adds, plus the autograd bookkeeping of ~10 nodes.
+In forward the projection branch bn_d(conv_d(x)) of a strided block (a 1x1 stride-2 convolution at 13 - 50 TFLOP/s and a
+small BatchNorm: launches that leave most of the chip idle) is issued on the side stream beside conv1 -> bn1 -> conv2
+(round 6: +1.2 % on the ResNet-18 step; bit-identical results, tests/test_classification_gpu.py).
 
 `fused_basic_block(blk, x)` returns None when the block cannot take this path (non-fp32 / CPU tensors, autocast,
 SyncBatchNorm, shapes outside the convolution kernels' tiling domain — probed once per input shape); the module

@@ -1522,6 +1522,9 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const float *__restrict__ par
   }
 }
 
+#ifndef SALUN_TN_TARGET
+#define SALUN_TN_TARGET 512  // workgroups a launch is split up to (lab builds: other targets, profiles/r06_sd_split_targets.txt)
+#endif
 struct TnPlan { int variant, ta, tb, rst, tiles_a, tiles_b, stages, splits, per_split; };
 
 // variant 1: 128 x 128, 64-token stages x 3 (96 KB, one workgroup per CU); 2: 128 x 128, 32-token stages x 4 (64 KB, two
@@ -1536,7 +1539,7 @@ TnPlan tn_plan(int64_t M, int Na, int Nb, int variant) {
   p.stages = (int)((M + p.rst - 1) / p.rst);
   const int tiles = p.tiles_a * p.tiles_b;
   const int min_stages = 256 / p.rst;           // a split reduces over >= 256 tokens
-  int splits = (512 + tiles - 1) / tiles;
+  int splits = (SALUN_TN_TARGET + tiles - 1) / tiles;
   if (splits > p.stages / min_stages) splits = p.stages / min_stages;
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;

@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const float *__restrict__ par
 }
 
 #ifndef SALUN_TN_TARGET
-#define SALUN_TN_TARGET 512  // workgroups a launch is split up to (lab builds: other targets, profiles/r06_sd_split_targets.txt)
+#define SALUN_TN_TARGET 256  // workgroups a launch is split up to: 512 until backward-weight moved to the side stream (profiles/r06_sd_split_targets.txt)
 #endif
 struct TnPlan { int variant, ta, tb, rst, tiles_a, tiles_b, stages, splits, per_split; };
 

@@ -874,9 +874,12 @@ bool supported(int C, int K, int R, int stride, int pad) {
 // leaves most CUs without a workgroup, and a lone workgroup pays the full memory latency on every stage; splitting
 // the (tap, channel) reduction over blockIdx.z fills the chip (target: 3 workgroups per CU) at the price of one fp32
 // round trip of the output tile.
+#ifndef SALUN_BF16_SPLIT_TARGET
+#define SALUN_BF16_SPLIT_TARGET 768  // lab builds: other targets (profiles/r06_sd_split_targets.txt)
+#endif
 struct SplitPlan { int splits, per; };
 SplitPlan plan_split(int tiles, int nstage) {
-  int s = 768 / (tiles < 1 ? 1 : tiles);
+  int s = SALUN_BF16_SPLIT_TARGET / (tiles < 1 ? 1 : tiles);
   if (s > nstage / 6) s = nstage / 6;  // at least 6 stages per workgroup
   if (s > 16) s = 16;
   if (s < 1) s = 1;

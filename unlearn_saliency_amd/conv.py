@@ -96,7 +96,7 @@ class _ConvFn(FastFunction):
             if overlap:
                 main, side = torch.cuda.current_stream(dy.device), resblock._side_stream(dy.device)
                 side.wait_stream(main)
-                with torch.cuda.stream(side):
+                with resblock._on_side(side, dst is None):
                     dw = ops.conv2d_backward_weight(x, dy, w.shape, stride, pad, out=dst, accumulate=True, shared=True)
                 if dw is None:  # outside the kernel's domain after all: nothing was launched
                     overlap = False

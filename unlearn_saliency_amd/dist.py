@@ -61,7 +61,19 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+            if os.environ.get("SALUN_RCCL_HIGH_PRIORITY", "1") != "0":
+                # the communicator's stream from the HIGH-priority pool: see the note behind init_process_group
+                try:
+                    opts = dist.ProcessGroupNCCL.Options()
+                    opts.is_high_priority_stream = True
+                    kw["pg_options"] = opts
+                except Exception:  # a torch without the option object: default stream
+                    pass
         dist.init_process_group(backend=backend, rank=rk, world_size=ws, **kw)
+        # (High-priority communicator stream, round 6: the data-parallel ResNet-18 step at world size 1 read 12.5 ms instead
+        # of 8.7 in 3 of 26 runs with the default stream and in 1 of 60 with this one — same box, interleaved.  The slow
+        # state is not one the pairwise stream probes of streams.py detect (they pass in it); what is known: it needs the
+        # collectives' queue, it is decided at start-up, and rocprofv3 attached changes which runs show it.)
         if backend == "nccl":
             # side streams (backward-weight, the diffusion steps' target pass, the collectives' launch stream) probed NOW, on every rank at the same
             # point, because their probe includes collectives (streams.py)

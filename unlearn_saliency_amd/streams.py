@@ -24,7 +24,7 @@ import torch
 _PROBE = os.environ.get("SALUN_STREAM_PROBE", "1") != "0"
 _keep: list = []   # rejected candidates stay alive: torch hands streams out of a pool, a freed one would come back
 STATS = {"probes": 0, "rejected": 0}
-_DP_CANDIDATES = 4  # candidates every rank probes under a process group
+_DP_CANDIDATES = int(os.environ.get("SALUN_STREAM_CANDIDATES", "4"))  # candidates every rank probes under a process group
 _accepted: dict = {}  # device -> side streams handed out so far: a new one must run beside each of them too (the
                       # diffusion steps keep two: backward-weight and the no-grad target pass; sharing one queue cost the
                       # data-parallel DDPM step 19 % — 126 vs 106 ms — although the two are busy in different phases)
@@ -74,6 +74,28 @@ def _beside_collectives(main, cand, buf, probe) -> bool:
     return e_coll.elapsed_time(e_end) > 0.5
 
 
+def _collective_beside_main(main, launcher, buf, probe) -> bool:
+    """The pairing the candidate probes do not cover: the COMMUNICATOR's stream against the compute stream.  With the compute
+    stream busy, a small all-reduce issued from the idle `launcher` stream must complete before that work ends; if it does
+    not, the communicator's kernels sit in the compute stream's hardware queue, and in a training step a gradient slice's
+    all-reduce (which waits for the backward-weight stream) would hold back every later kernel of the compute stream."""
+    import torch.distributed as dist
+    main.synchronize()
+    launcher.synchronize()
+    e_end = torch.cuda.Event(enable_timing=True)
+    e_coll = torch.cuda.Event(enable_timing=True)
+    _busy(main, buf)
+    e_end.record(main)
+    with torch.cuda.stream(launcher):
+        work = dist.all_reduce(probe, async_op=True)
+        work.wait()
+        e_coll.record(launcher)
+    main.synchronize()
+    launcher.synchronize()
+    return e_coll.elapsed_time(e_end) > 0.5
+
+
+COLLECTIVES_BESIDE_MAIN: dict = {}   # device -> what the check above found (prepare())
 _pool: dict = {}      # device -> streams probed by prepare() (incl. against the communicator) and not handed out yet
 
 
@@ -85,6 +107,17 @@ def prepare(device, count: int = 2) -> None:
         return
     for _ in range(count):
         _pool.setdefault(dev, []).append(_probe(dev, 8, True))
+    import torch.distributed as dist
+    # diagnostic (set SALUN_STREAM_DEBUG on EVERY rank or on none: the check issues a collective)
+    if (os.environ.get("SALUN_STREAM_DEBUG") and dist.is_available() and dist.is_initialized()
+            and dist.get_backend() == "nccl" and _pool.get(dev)):
+        with torch.cuda.device(dev):
+            buf = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=dev).zero_()
+            probe = torch.zeros(1024, dtype=torch.float32, device=dev)
+            ok = _collective_beside_main(torch.cuda.current_stream(dev), _pool[dev][-1], buf, probe)
+        COLLECTIVES_BESIDE_MAIN[dev] = ok
+        import sys
+        print(f"streams: the communicator's stream runs beside the compute stream: {ok}", file=sys.stderr)
 
 
 def concurrent_stream(device, tries: int = 8) -> "torch.cuda.Stream":
@@ -136,5 +169,10 @@ def _probe(dev, tries: int, with_collectives: bool) -> "torch.cuda.Stream":
                 STATS["rejected"] += 0 if ok else 1
                 _keep.append(cand)
         # nothing passed (a one-queue configuration): any stream is as good as another
+        if chosen is None:
+            STATS["fallbacks"] = STATS.get("fallbacks", 0) + 1
+            if os.environ.get("SALUN_STREAM_DEBUG"):
+                import sys
+                print(f"streams: NO candidate of {_DP_CANDIDATES if dp else tries} passed (collectives={dp}): taking the first", file=sys.stderr)
         _accepted.setdefault(dev, []).append(chosen or first)
         return chosen or first

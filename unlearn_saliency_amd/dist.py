@@ -219,7 +219,6 @@ class BucketedGradReducer:
         self.arrived = [0] * len(self.bounds)
         self.launched = [False] * len(self.bounds)
         self.works = []
-        self._aux = {}          # device -> the stream the slices' collectives are issued from (see _launch)
         self._order = []        # bucket indices in the order this step launched them (always descending)
         self._next = len(self.bounds) - 1  # the next slice allowed to go out
         self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -251,25 +250,22 @@ class BucketedGradReducer:
         self._order.append(b)
         if dist.get_backend() == "nccl":
             # The weight-gradient kernels of this slice may still be queued on the backward-weight side stream
-            # (resblock.py / conv.py overlap them with backward-data).  The collective must wait for them — but the
-            # MAIN stream must not: a join per block (rounds 1 - 5) cost the data-parallel step 17 % at world size 1
-            # (10.0 vs 8.5 ms, bench.py --force_collectives).  So the collective is issued from a launch stream that
-            # has waited for both; RCCL orders its own stream behind the stream it is called on.
+            # (resblock.py / conv.py / conv_bf16.py overlap them with backward-data).  The collective must wait for them —
+            # but the MAIN stream must not: a join per block (rounds 1 - 5) cost the data-parallel step 17 % at world size
+            # 1 (10.0 vs 8.5 ms).  So the collective is issued FROM THE SIDE STREAM, after that stream has been told to
+            # wait for the main stream's work so far (the normalisation / bias gradients of the slice; the side stream lags
+            # the main one anyway and does the same wait before every backward-weight launch): RCCL orders its own
+            # stream behind the stream it is called on, the side stream goes on with the next layers' kernels.
+            # (Until late in round 6 a separate launch stream waited for both.  One more busy hardware queue: with it the
+            # step was 8.65 ms, 9.7 ms in EVERY run once the stream probes created 24 instead of 12 candidate streams, and
+            # 12.5 ms in 1 - 10 % of processes; from the side stream 8.60 ms in all three situations.)
             dev = sl.device
             side = _wgrad_side_stream(dev)
             if side is None:
                 self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.AVG, async_op=True), None))
             else:
-                aux = self._aux.get(dev)
-                if aux is None:
-                    # a stream with a hardware queue of its own, like the side streams: on the compute stream's queue
-                    # its wait for the side stream would hold back every later kernel of the compute stream (seen:
-                    # 9.9 instead of 8.7 ms per step)
-                    from . import streams
-                    aux = self._aux[dev] = streams.concurrent_stream(dev)
-                aux.wait_stream(torch.cuda.current_stream(dev))
-                aux.wait_stream(side)
-                with torch.cuda.stream(aux):
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
                     self.works.append((dist.all_reduce(sl, op=dist.ReduceOp.AVG, async_op=True), None))
         else:
             if sl.is_cuda:  # gloo stages device tensors through the host behind the CURRENT stream only

@@ -260,9 +260,10 @@ class Diffusion(object):
             xt = q_sample(forget_x, t, e, b)
             pseudo_c = torch.full(forget_c.shape, (args.label_to_forget + 1) % 10, device=forget_c.device)
             tf = t.float()
-            # (not under data parallel: beside the communicator's stream and the gradient hooks the second stream made
-            # the step SLOWER — 122 vs 107 ms at world size 1, round 6 — where single-process it gains 0.5 %)
-            side = _target_stream(xt.device) if (PSEUDO_OVERLAP and xt.is_cuda and not sdist.collectives_on()) else None
+            # (also under data parallel: it was switched off there while the gradient slices' collectives had a launch stream
+            # of their own — 122 vs 107 ms at world size 1 with both; with the collectives issued from the backward-weight
+            # stream, dist.BucketedGradReducer, it gains 2 %: 107.6 -> 105.5 ms)
+            side = _target_stream(xt.device) if (PSEUDO_OVERLAP and xt.is_cuda) else None
             if side is not None:
                 # the no-grad target pass depends only on (xt, t): it runs on its own stream NEXT TO the forward pass
                 # that is differentiated, filling the phases where one pass leaves the chip half empty (4x4 / 8x8

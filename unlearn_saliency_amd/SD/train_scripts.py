@@ -152,11 +152,10 @@ def forget_and_target(model, z_noisy, t, c_forget, c_target):
     after an optimizer step — the remain pass, in every loop of this file; if the forget pass had to pack anything
     (cold cache) the target pass is issued on the main stream after it instead."""
     dev = z_noisy.device
-    # Under data parallel the target pass stays on the compute stream, as in the DDPM runner: beside the backward-weight
-    # side stream, the collectives' launch stream and the communicator's own stream a fourth busy stream made the step
-    # SLOWER (round 6, RCCL at world size 1, same box: 174.8 ms with it, 167.4 without; activations resident 171.4 /
-    # 139.7; single process 158 / 130 — the hardware-queue arbitration of §5, not arithmetic)
-    if not (TARGET_OVERLAP and z_noisy.is_cuda) or sdist.collectives_on():
+    # (Also under data parallel.  While the gradient slices' collectives had a launch stream of their own, this second
+    # stream made the data-parallel step slower — 174.8 ms with it, 167.4 without — and was switched off there; with the
+    # collectives issued from the backward-weight stream it gains what it gains single-process: 164.4 -> 158.8 ms.)
+    if not (TARGET_OVERLAP and z_noisy.is_cuda):
         out = model.apply_model(z_noisy, t, c_forget)
         with torch.no_grad():
             return out, model.apply_model(z_noisy, t, c_target)

@@ -75,7 +75,7 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
         # state is not one the pairwise stream probes of streams.py detect (they pass in it); what is known: it needs the
         # collectives' queue, it is decided at start-up, and rocprofv3 attached changes which runs show it.)
         if backend == "nccl":
-            # side streams (backward-weight, the diffusion steps' target pass, the collectives' launch stream) probed NOW, on every rank at the same
+            # side streams (backward-weight, the diffusion steps' target pass, one spare) probed NOW, on every rank at the same
             # point, because their probe includes collectives (streams.py)
             from . import streams
             streams.prepare(kw["device_id"], 3)

@@ -71,9 +71,10 @@ def init_from_env(backend: Optional[str] = None) -> tuple[int, int, int]:
                     pass
         dist.init_process_group(backend=backend, rank=rk, world_size=ws, **kw)
         # (High-priority communicator stream, round 6: the data-parallel ResNet-18 step at world size 1 read 12.5 ms instead
-        # of 8.7 in 3 of 26 runs with the default stream and in 1 of 60 with this one — same box, interleaved.  The slow
-        # state is not one the pairwise stream probes of streams.py detect (they pass in it); what is known: it needs the
-        # collectives' queue, it is decided at start-up, and rocprofv3 attached changes which runs show it.)
+        # of 8.7 in 3 of 26 runs with the default stream and in 1 of 60 with this one — interleaved; later series put the
+        # rate with it at ~3 %, so the evidence for the option is weak.  The slow state is not one the pairwise stream
+        # probes of streams.py detect (they pass in it); it is decided at start-up, and rocprofv3 attached changes which
+        # runs show it.)
         if backend == "nccl":
             # side streams (backward-weight, the diffusion steps' target pass, one spare) probed NOW, on every rank at the same
             # point, because their probe includes collectives (streams.py)
@@ -257,8 +258,9 @@ class BucketedGradReducer:
             # the main one anyway and does the same wait before every backward-weight launch): RCCL orders its own
             # stream behind the stream it is called on, the side stream goes on with the next layers' kernels.
             # (Until late in round 6 a separate launch stream waited for both.  One more busy hardware queue: with it the
-            # step was 8.65 ms, 9.7 ms in EVERY run once the stream probes created 24 instead of 12 candidate streams, and
-            # 12.5 ms in 1 - 10 % of processes; from the side stream 8.60 ms in all three situations.)
+            # step was 8.65 ms, and 9.7 ms in EVERY run once the stream probes created 24 instead of 12 candidate streams;
+            # from the side stream 8.60 ms in both.  A rare 12.4 ms state — ~3 % of processes, decided at start-up, cause
+            # unknown — exists with either form: profiles/r06_dp_outliers.txt.)
             dev = sl.device
             side = _wgrad_side_stream(dev)
             if side is None:

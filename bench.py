@@ -321,8 +321,8 @@ def dp_ws1_line(extra, plain_ms):
 
 def dp_ws1_checked(extra, plain_ms):
     """dp_ws1_line, run a second time when the first reading is more than 15 % above the single-process step: a process
-    occasionally starts in a slow arbitration state of the hardware queues (12.5 ms instead of 8.7 for ResNet-18: 1 of 60
-    processes with the communicator's stream at high priority).  Both readings stay in the block
+    occasionally starts in a slow arbitration state of the hardware queues (12.4 ms instead of 8.6 for ResNet-18: about 3 %
+    of processes, cause unknown).  Both readings stay in the block
     (`attempts_ms`); the fields are the faster one's."""
     first = dp_ws1_line(extra, plain_ms)
     if "error" in first or not first.get("dp_over_plain") or first["dp_over_plain"] <= 1.15:

@@ -151,6 +151,7 @@ def _probe(dev, tries: int, with_collectives: bool) -> "torch.cuda.Stream":
             dist.all_reduce(probe)      # communicator set-up, if this is the process group's first collective
             main.synchronize()
         first = chosen = None
+        verdicts = []   # per candidate: passed every check? (SALUN_STREAM_DEBUG)
         for _ in range(_DP_CANDIDATES if dp else tries):
             cand = torch.cuda.Stream(device=dev)
             first = first or cand
@@ -160,6 +161,7 @@ def _probe(dev, tries: int, with_collectives: bool) -> "torch.cuda.Stream":
                 ok = _beside_main(prev, cand, buf, flag) and ok
             if dp:                       # every rank issues this collective for every candidate, accepted or not
                 ok = _beside_collectives(main, cand, buf, probe) and ok
+            verdicts.append(bool(ok))
             if ok and chosen is None:
                 chosen = cand
                 if not dp:
@@ -169,6 +171,9 @@ def _probe(dev, tries: int, with_collectives: bool) -> "torch.cuda.Stream":
                 STATS["rejected"] += 0 if ok else 1
                 _keep.append(cand)
         # nothing passed (a one-queue configuration): any stream is as good as another
+        if os.environ.get("SALUN_STREAM_DEBUG"):
+            import sys
+            print(f"streams: probe verdicts {verdicts} (collectives={dp})", file=sys.stderr)
         if chosen is None:
             STATS["fallbacks"] = STATS.get("fallbacks", 0) + 1
             if os.environ.get("SALUN_STREAM_DEBUG"):
